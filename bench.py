@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the sampler hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2] [--kappa 0.5]
+
+One step = one pass of the hot path over one batch of synthetic input, through the reference's
+operator surface: ``GaussianSampler.preprocess(...)`` + one fused launch producing u, grad u and
+the Hessian (orders 0..2) for every sample point.  Inputs are resident in HBM before the timed
+region.  N > 1: launched by torch.distributed.run, one rank per GPU; the sample grid is sharded
+by rows (weak scaling: every rank owns a res x res block of a res x (N res) grid over the same
+65k Gaussians); the forward needs no collective, the backward all-reduces the parameter
+gradients (reported in the extra ``fwd_bwd`` field, not part of the timed K steps).
+
+Prints ONE JSON line on rank 0 (contract in the task description): metric, value (whole-job
+sample-points/s), roofline of the dominant kernel (HBM-bound designation of BASELINE.json),
+cpu_baseline (the reference's dense PyTorch algorithm on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+VALU_PAIR_PEAK = 3.6e12    # pairs/s: 157.3 TFLOP/s fp32 / 2 / ~22 issue slots per pair
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--kappa", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bwd", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(gs, pts, budget_pairs=1.3e8):
+    """The reference's dense PyTorch algorithm (oracle/dense_torch.py) on the host cores, on a
+    bounded slice of the same workload; linear in M, so points/s extrapolates."""
+    from oracle import dense_torch
+    cores = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    N = gs["means"].shape[0]
+    m = int(max(256, min(pts.shape[0], budget_pairs // N)))
+    m -= m % 256
+    sl = pts[:: max(1, pts.shape[0] // m)][:m].float().contiguous()
+    args = (gs["means"].float(), gs["conics"].float(), gs["values"].float(), sl)
+    dense_torch.forward(*[a[:256] if i == 3 else a for i, a in enumerate(args)])  # warm-up
+    t0 = time.perf_counter()
+    dense_torch.forward(*args, orders=(0, 1, 2), chunk=256)
+    dt = time.perf_counter() - t0
+    return {
+        "value": m / dt, "unit": "sample-points/s", "cores": cores, "kind": "port",
+        "sample": f"{m} of {pts.shape[0]} points x {N} Gaussians, orders 0-2, fp32, "
+                  f"torch dense (reference algorithm, oracle/dense_torch.py), {dt:.1f} s, linear in M",
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import pigs_amd
+    pigs_amd.build()
+    from diff_gaussian_sampling import GaussianSampler
+    from pigs_amd import synthetic, sampler as S
+
+    # ---------------- workload (seeded, generated on the CPU, then moved) ----------------
+    if a.workload == "c3":
+        nx = ny = 256
+        res = 1024
+    else:
+        nx, ny, res = 128, 64, 256
+    gs = synthetic.lattice_gaussians(nx, ny, a.kappa, seed=0)
+    # weak scaling: rank r owns rows [r*res, (r+1)*res) of a res x (world*res) grid over [-1,1]^2
+    pts = synthetic.grid_samples(res, res * world, row0=rank * res, rows=res)
+    N, M = gs["means"].shape[0], pts.shape[0]
+    t = {k: v.float().to(dev) for k, v in gs.items()}
+    pts_d = pts.float().to(dev)
+    sampler = GaussianSampler(False, fuse="all")
+
+    def step():
+        sampler.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
+        return sampler.sample((0, 1, 2))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = M * world / (dt / a.steps)
+
+    # ---------------- dominant kernel: HIP events on the launch stream ----------------
+    means, values, conics, samples = sampler._inputs
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        S.forward_raw(means, values, conics, samples, 7)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(a.steps):
+            S.forward_raw(means, values, conics, samples, 7)
+        e1.record()
+        torch.cuda.synchronize(dev)
+    kernel_s = e0.elapsed_time(e1) / a.steps * 1e-3
+    algo_bytes = 24 * N + 36 * M       # fp32, d=2, c=1: 6 floats/Gaussian + (2 in + 7 out) floats/point
+    achieved = algo_bytes / kernel_s
+    roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "kernel": "dense_forward_kernel<float,2,1,7>", "kernel_ms": kernel_s * 1e3,
+                "algorithmic_bytes": algo_bytes,
+                "valu_frac_dense_pairs": N * M / kernel_s / VALU_PAIR_PEAK}
+
+    # ---------------- fwd + bwd step (second half of BASELINE.json's metric) ----------------
+    fwd_bwd = None
+    if not a.no_bwd:
+        req = {k: t[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
+
+        def train_step():
+            sampler.preprocess(req["means"], req["values"], t["covariances"], req["conics"], pts_d)
+            u, ux, uxx = sampler.sample((0, 1, 2))
+            # diffusion residual shape of test_no_mlp.py:144 (u_t replaced by u: same data flow)
+            loss = ((u[:, 0] - (uxx[:, 0, 0, 0] + uxx[:, 1, 1, 0])) ** 2).mean() + (ux ** 2).mean()
+            grads = torch.autograd.grad(loss, list(req.values()))
+            if dist is not None:
+                flat = torch.cat([g.reshape(N, -1) for g in grads], dim=1)   # one [N,6] buffer, one all-reduce
+                dist.all_reduce(flat)
+            return grads
+
+        nb = max(1, min(a.steps, 3 if a.workload == "c3" else 10))
+        train_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            train_step()
+        barrier()
+        fwd_bwd = {"ms_per_step": (time.perf_counter() - t0) / nb * 1e3, "steps": nb,
+                   "what": "preprocess + fused fwd(0..2) + residual loss + fused bwd"
+                           + (" + all-reduce of [N,6] grads" if dist is not None else "")}
+
+    line = {
+        "metric": "sample-points/sec (fwd + 1st + 2nd derivatives, fused)", "value": value,
+        "unit": "sample-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded lattice Gaussians, regular sample grid)",
+        "config": {"workload": f"{a.workload}: {N} Gaussians x {res}x{res} grid per GPU, d=2, c=1, "
+                               f"kappa={a.kappa}, orders 0-2", "gaussians": N, "points_per_gpu": M,
+                   "kappa": a.kappa, "path": "dense", "step": "preprocess + fused forward (orders 0..2)"},
+        "roofline": roofline, "fwd_bwd": fwd_bwd,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(gs, pts)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

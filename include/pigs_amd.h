@@ -1,0 +1,72 @@
+/*
+ * pigs_amd -- C ABI of the MI355X-native differentiable Gaussian sampler.
+ *
+ * This is the drop-in boundary for the hot path of kr4b/pigs: the native half of
+ * `diff_gaussian_sampling.GaussianSampler`.  The reference's own native extension is an
+ * un-vendored submodule (/root/reference/.gitmodules:1-3), so its C++ interface cannot be
+ * cited; each entry point below replaces the native work behind one Python-visible method of
+ * that class, cited by its call sites:
+ *
+ *   pigs_sample_forward   GaussianSampler.sample_gaussians()                (model_pn.py:650,770; test_gaussian_sampling.py:57)
+ *                         .sample_gaussians_derivative()                    (model_pn.py:651,771; test_derivatives.py:124)
+ *                         .sample_gaussians_laplacian()  [full Hessian]     (model_pn.py:652,772; test_derivatives.py:220)
+ *                         .sample_gaussians_third_derivative()              (model_pn.py:654,778; test_pde.py:53)
+ *   pigs_sample_backward  autograd backward of those outputs wrt (means, values, conics)
+ *                         (test_derivatives.py:123,214-215,349-352; main_pn.py:220; test_no_mlp.py:146)
+ *   pigs_plan_*           GaussianSampler.preprocess(means, values, covariances, conics, samples)
+ *                         (model_pn.py:648,768,784; test_gaussian_sampling.py:56; test_1d.py:30)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP), row-major contiguous; nothing here takes or
+ *     returns a torch type.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all calls are asynchronous on `stream`; none allocates, frees or synchronises, so they
+ *     can be captured into a hipGraph.
+ *   - layouts: means[N][d], conics[N][d(d+1)/2] (upper triangle row-major: d=2 -> xx,xy,yy,
+ *     gaussians.py:186-189), values[N][c], samples[M][d];
+ *     out0[M][c], out1[M][d][c], out2[M][d][d][c], out3[M][d][d][d][c]  (model_pn.py:650-654).
+ *   - orders_mask: bit k set = derivative order k is requested (outputs) / has an incoming
+ *     gradient (backward).  Pointers of orders outside the mask may be NULL.
+ *   - supported: d in {1,2}, c in {1..4}, dtype f32/f64 (binned plan: d=2, f32).
+ *   - return value: PIGS_OK or an error code; pigs_status_string() names it.
+ */
+#ifndef PIGS_AMD_H
+#define PIGS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIGS_ABI_VERSION 1
+
+enum pigs_status {
+    PIGS_OK = 0,
+    PIGS_ERR_INVALID = 1,      /* bad argument (negative size, null required pointer, ...) */
+    PIGS_ERR_UNSUPPORTED = 2,  /* d / c / dtype / mask combination not compiled            */
+    PIGS_ERR_LAUNCH = 3,       /* HIP reported a launch / memset error                     */
+    PIGS_ERR_WORKSPACE = 4     /* workspace too small for the plan                         */
+};
+
+enum pigs_dtype { PIGS_F32 = 0, PIGS_F64 = 1 };
+
+int pigs_abi_version(void);
+const char* pigs_status_string(int status);
+
+/* Dense forward: out_k = sum over ALL N Gaussians (exact reference semantics, no culling). */
+int pigs_sample_forward(int dtype, int d, int c, int orders_mask, int64_t N, int64_t M,
+                        const void* means, const void* conics, const void* values, const void* samples,
+                        void* out0, void* out1, void* out2, void* out3, void* stream);
+
+/* Dense backward: gradients of sum_k <gout_k, out_k> wrt means [N][d], flat conics
+ * [N][d(d+1)/2] and values [N][c].  The three gradient buffers are overwritten. */
+int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, int64_t M,
+                         const void* means, const void* conics, const void* values, const void* samples,
+                         const void* gout0, const void* gout1, const void* gout2, const void* gout3,
+                         void* g_means, void* g_conics, void* g_values, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIGS_AMD_H */

@@ -1,0 +1,56 @@
+"""ctypes binding of the C ABI in include/pigs_amd.h (pigs_amd/libpigs_amd.so).
+
+There is no fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpigs_amd.so")
+
+PIGS_F32, PIGS_F64 = 0, 1
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/pigs_amd.h declares
+SIGNATURES = {
+    "pigs_abi_version": (_i, []),
+    "pigs_status_string": (ctypes.c_char_p, [_i]),
+    "pigs_sample_forward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp]),
+    "pigs_sample_backward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp] * 3 + [_vp]),
+}
+
+_lib = None
+
+
+class PigsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle of libpigs_amd.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP library first (python -m pigs_amd.build). "
+            "pigs_amd has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pigs_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.pigs_abi_version()} != {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pigs_status_string(status).decode()
+        raise PigsError(f"{what}: {msg} (status {status})")

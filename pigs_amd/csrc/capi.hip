@@ -1,0 +1,64 @@
+// extern "C" entry points declared in include/pigs_amd.h: argument checks + dispatch.
+#include "launch.h"
+
+using namespace pigs;
+
+static int check_common(int dtype, int d, int c, int mask, int64_t N, int64_t M, const void* means,
+                        const void* conics, const void* values, const void* samples) {
+    if (dtype != PIGS_F32 && dtype != PIGS_F64) return PIGS_ERR_UNSUPPORTED;
+    if (d < 1 || c < 1 || N < 0 || M < 0 || mask <= 0 || mask > 15) return PIGS_ERR_INVALID;
+    if (d > 2 || c > 4) return PIGS_ERR_UNSUPPORTED;
+    if (N > 0 && (!means || !conics || !values)) return PIGS_ERR_INVALID;
+    if (M > 0 && !samples) return PIGS_ERR_INVALID;
+    return PIGS_OK;
+}
+
+extern "C" {
+
+int pigs_abi_version(void) { return PIGS_ABI_VERSION; }
+
+const char* pigs_status_string(int status) {
+    switch (status) {
+        case PIGS_OK: return "ok";
+        case PIGS_ERR_INVALID: return "invalid argument";
+        case PIGS_ERR_UNSUPPORTED: return "unsupported d/c/dtype/orders combination";
+        case PIGS_ERR_LAUNCH: return "HIP launch error";
+        case PIGS_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+int pigs_sample_forward(int dtype, int d, int c, int orders_mask, int64_t N, int64_t M, const void* means,
+                        const void* conics, const void* values, const void* samples, void* out0, void* out1,
+                        void* out2, void* out3, void* stream) {
+    int rc = check_common(dtype, d, c, orders_mask, N, M, means, conics, values, samples);
+    if (rc != PIGS_OK) return rc;
+    void* outs[4] = {out0, out1, out2, out3};
+    for (int k = 0; k < 4; ++k)
+        if ((orders_mask >> k & 1) && M > 0 && !outs[k]) return PIGS_ERR_INVALID;
+    SampleArgs a{};
+    a.dtype = dtype; a.d = d; a.c = c; a.orders_mask = orders_mask; a.N = N; a.M = M;
+    a.means = means; a.conics = conics; a.values = values; a.samples = samples;
+    for (int k = 0; k < 4; ++k) a.out[k] = (orders_mask >> k & 1) ? outs[k] : nullptr;
+    return dense_dispatch(false, a, (hipStream_t)stream);
+}
+
+int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, int64_t M, const void* means,
+                         const void* conics, const void* values, const void* samples, const void* gout0,
+                         const void* gout1, const void* gout2, const void* gout3, void* g_means, void* g_conics,
+                         void* g_values, void* stream) {
+    int rc = check_common(dtype, d, c, orders_mask, N, M, means, conics, values, samples);
+    if (rc != PIGS_OK) return rc;
+    const void* gs[4] = {gout0, gout1, gout2, gout3};
+    for (int k = 0; k < 4; ++k)
+        if ((orders_mask >> k & 1) && M > 0 && !gs[k]) return PIGS_ERR_INVALID;
+    if (N > 0 && (!g_means || !g_conics || !g_values)) return PIGS_ERR_INVALID;
+    SampleArgs a{};
+    a.dtype = dtype; a.d = d; a.c = c; a.orders_mask = orders_mask; a.N = N; a.M = M;
+    a.means = means; a.conics = conics; a.values = values; a.samples = samples;
+    for (int k = 0; k < 4; ++k) a.gout[k] = (orders_mask >> k & 1) ? gs[k] : nullptr;
+    a.g_means = g_means; a.g_conics = g_conics; a.g_values = g_values;
+    return dense_dispatch(true, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

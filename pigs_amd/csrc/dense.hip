@@ -1,0 +1,254 @@
+// Dense (no culling) sampler kernels: every sample point against every Gaussian.
+//
+// This is the exact restatement of the reference semantics (gaussians.py:48-58, 89-116) on the
+// GPU and the path taken for small problems (the PINN training loops call the sampler with
+// N ~ 1e3 Gaussians x M ~ 1e3 points: model_pn.py:768-772, test_no_mlp.py:104-125) and for
+// float64 (gradcheck, test_derivatives.py:96-106).  Large N x M goes through the binned path
+// (binned.hip).
+//
+// Forward:  lane = sample point, Gaussian parameters are wave-uniform and arrive through the
+//           scalar data path (s_load) -- no LDS or VGPR traffic per Gaussian.  The NW waves of
+//           a workgroup split the Gaussian range and are summed through LDS in a fixed order.
+// Backward: lane = Gaussian (its parameters and 5+c gradient accumulators live in VGPRs),
+//           sample points and incoming gradients are wave-uniform scalar loads, so no
+//           cross-lane reduction is needed.  Waves split the point range; workgroups that
+//           share a Gaussian block (gridDim.y > 1) combine with float atomics.
+#include "pair_math.h"
+#include "launch.h"
+
+namespace pigs {
+
+template <typename T, int D, int C, int MASK, int NW>
+__global__ __launch_bounds__(NW * 64) void dense_forward_kernel(
+    int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics,
+    const T* __restrict__ values, const T* __restrict__ samples, T* __restrict__ o0, T* __restrict__ o1,
+    T* __restrict__ o2, T* __restrict__ o3) {
+    using L = FwdLayout<D, C, MASK>;
+    constexpr int NF = Sym<D>::NF;
+    __shared__ T red[(NW > 1 ? NW - 1 : 1) * L::N * 64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t m = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = m < M;
+
+    T s[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = valid ? samples[m * D + i] : T(0);
+
+    T acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = T(0);
+
+    for (int64_t n = wave; n < N; n += NW) {
+        T mu[D], con[NF], v[C];
+#pragma unroll
+        for (int i = 0; i < D; ++i) mu[i] = means[n * D + i];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) con[i] = conics[n * NF + i];
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = values[n * C + i];
+        fwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v);
+    }
+
+    if constexpr (NW > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int k = 0; k < L::N; ++k) red[((wave - 1) * L::N + k) * 64 + lane] = acc[k];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < NW - 1; ++w) {
+#pragma unroll
+                for (int k = 0; k < L::N; ++k) acc[k] += red[(w * L::N + k) * 64 + lane];
+            }
+        }
+    }
+    if (wave == 0 && valid) fwd_store<T, D, C, MASK>(acc, m, o0, o1, o2, o3);
+}
+
+template <typename T, int D, int C, int MASK, int NW>
+__global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
+    int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics,
+    const T* __restrict__ values, const T* __restrict__ samples, const T* __restrict__ G0,
+    const T* __restrict__ G1, const T* __restrict__ G2, const T* __restrict__ G3, T* __restrict__ g_means,
+    T* __restrict__ g_conics, T* __restrict__ g_values) {
+    using L = BwdLayout<D, C>;
+    constexpr int NF = Sym<D>::NF;
+    __shared__ T red[(NW > 1 ? NW - 1 : 1) * L::N * 64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = n < N;
+    const int64_t nn = valid ? n : 0;
+
+    T mu[D], con[NF], v[C];
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu[i] = means[nn * D + i];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) con[i] = conics[nn * NF + i];
+#pragma unroll
+    for (int i = 0; i < C; ++i) v[i] = values[nn * C + i];
+
+    T acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = T(0);
+
+    // this workgroup's slice of the points, split again over its waves
+    const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t m_begin = (int64_t)blockIdx.y * per;
+    const int64_t m_end = m_begin + per < M ? m_begin + per : M;
+    for (int64_t m = m_begin + wave; m < m_end; m += NW) {
+        T s[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s[i] = samples[m * D + i];
+        Gsym<T, D, C, MASK> G;
+        G.load(m, G0, G1, G2, G3);
+        bwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v, G);
+    }
+
+    if constexpr (NW > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int k = 0; k < L::N; ++k) red[((wave - 1) * L::N + k) * 64 + lane] = acc[k];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < NW - 1; ++w) {
+#pragma unroll
+                for (int k = 0; k < L::N; ++k) acc[k] += red[(w * L::N + k) * 64 + lane];
+            }
+        }
+    }
+    if (wave == 0 && valid) {
+        if (gridDim.y == 1) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) g_means[n * D + i] = acc[L::MU + i];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) g_conics[n * NF + i] = acc[L::CON + i];
+#pragma unroll
+            for (int i = 0; i < C; ++i) g_values[n * C + i] = acc[L::VAL + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) atomicAdd(&g_means[n * D + i], acc[L::MU + i]);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) atomicAdd(&g_conics[n * NF + i], acc[L::CON + i]);
+#pragma unroll
+            for (int i = 0; i < C; ++i) atomicAdd(&g_values[n * C + i], acc[L::VAL + i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side launchers
+// ------------------------------------------------------------------------------------------
+
+template <typename T, int D, int C, int MASK>
+static int launch_dense_forward(const SampleArgs& a, hipStream_t stream) {
+    const int64_t blocks = (a.M + 63) / 64;
+    if (blocks == 0 ) return PIGS_OK;
+    if (blocks > 0x7fffffffLL) return PIGS_ERR_INVALID;
+    const T* means = (const T*)a.means; const T* conics = (const T*)a.conics;
+    const T* values = (const T*)a.values; const T* samples = (const T*)a.samples;
+    T* o0 = (T*)a.out[0]; T* o1 = (T*)a.out[1]; T* o2 = (T*)a.out[2]; T* o3 = (T*)a.out[3];
+    constexpr int NACC = FwdLayout<D, C, MASK>::N;
+    // few point blocks: spread the Gaussian loop over 16 waves per workgroup
+    constexpr bool can16 = (15 * NACC * 64 * sizeof(T) <= 60 * 1024);
+    if constexpr (can16) {
+      if (blocks < 1024 && a.N >= 64) {
+        hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream,
+                           a.N, a.M, means, conics, values, samples, o0, o1, o2, o3);
+        return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH;
+      }
+    }
+    {
+        hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 4>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           a.N, a.M, means, conics, values, samples, o0, o1, o2, o3);
+    }
+    return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH;
+}
+
+template <typename T, int D, int C, int MASK>
+static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
+    constexpr int NF = Sym<D>::NF;
+    const int64_t gblocks = (a.N + 63) / 64;
+    if (gblocks == 0) return PIGS_OK;
+    if (gblocks > 0x7fffffffLL) return PIGS_ERR_INVALID;
+    T* gm = (T*)a.g_means; T* gc = (T*)a.g_conics; T* gv = (T*)a.g_values;
+    if (a.M == 0) {
+        if (hipMemsetAsync(gm, 0, sizeof(T) * a.N * D, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
+        if (hipMemsetAsync(gc, 0, sizeof(T) * a.N * NF, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
+        if (hipMemsetAsync(gv, 0, sizeof(T) * a.N * C, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
+        return PIGS_OK;
+    }
+    // split the point range over gridDim.y so that ~2048 workgroups exist; each wave should
+    // still see >= 64 points
+    int64_t ysplit = 2048 / gblocks;
+    const int64_t max_split = (a.M + 4 * 64 - 1) / (4 * 64);
+    if (ysplit > max_split) ysplit = max_split;
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > 65535) ysplit = 65535;
+    if (ysplit > 1) {
+        if (hipMemsetAsync(gm, 0, sizeof(T) * a.N * D, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
+        if (hipMemsetAsync(gc, 0, sizeof(T) * a.N * NF, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
+        if (hipMemsetAsync(gv, 0, sizeof(T) * a.N * C, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((dense_backward_kernel<T, D, C, MASK, 4>), dim3((unsigned)gblocks, (unsigned)ysplit), dim3(256),
+                       0, stream, a.N, a.M, (const T*)a.means, (const T*)a.conics, (const T*)a.values,
+                       (const T*)a.samples, (const T*)a.gout[0], (const T*)a.gout[1], (const T*)a.gout[2],
+                       (const T*)a.gout[3], gm, gc, gv);
+    return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH;
+}
+
+// Smallest compiled order mask that covers the request.  Compiled: single orders, 0..2 and 0..3.
+static int covering_mask(int mask) {
+    if (mask == 1 || mask == 2 || mask == 4 || mask == 8) return mask;
+    if ((mask & ~7) == 0) return 7;
+    return 15;
+}
+
+template <typename T, int D, int C>
+static int dispatch_mask(bool backward, const SampleArgs& a, hipStream_t stream) {
+    // Orders inside the covering mask that were not requested have null output / gradient
+    // pointers: the forward skips their stores, the backward reads their gradients as zero.
+    const int mask = covering_mask(a.orders_mask);
+#define PIGS_CASE(MK)                                                                        \
+    case MK:                                                                                 \
+        return backward ? launch_dense_backward<T, D, C, MK>(a, stream)                      \
+                        : launch_dense_forward<T, D, C, MK>(a, stream);
+    switch (mask) {
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15)
+        default: break;
+    }
+#undef PIGS_CASE
+    return PIGS_ERR_UNSUPPORTED;
+}
+
+template <typename T, int D>
+static int dispatch_c(bool backward, const SampleArgs& a, hipStream_t stream) {
+    switch (a.c) {
+        case 1: return dispatch_mask<T, D, 1>(backward, a, stream);
+        case 2: return dispatch_mask<T, D, 2>(backward, a, stream);
+        case 3: return dispatch_mask<T, D, 3>(backward, a, stream);
+        case 4: return dispatch_mask<T, D, 4>(backward, a, stream);
+        default: return PIGS_ERR_UNSUPPORTED;
+    }
+}
+
+template <typename T>
+static int dispatch_d(bool backward, const SampleArgs& a, hipStream_t stream) {
+    switch (a.d) {
+        case 1: return dispatch_c<T, 1>(backward, a, stream);
+        case 2: return dispatch_c<T, 2>(backward, a, stream);
+        default: return PIGS_ERR_UNSUPPORTED;
+    }
+}
+
+int dense_dispatch(bool backward, const SampleArgs& a, hipStream_t stream) {
+    if (a.dtype == PIGS_F32) return dispatch_d<float>(backward, a, stream);
+    if (a.dtype == PIGS_F64) return dispatch_d<double>(backward, a, stream);
+    return PIGS_ERR_UNSUPPORTED;
+}
+
+}  // namespace pigs

@@ -1,0 +1,324 @@
+// Per-(sample point, Gaussian) arithmetic shared by every kernel of the sampler.
+//
+// Semantics follow the reference's dense PyTorch twin of its CUDA sampler:
+//   order 0  gaussians.sample_gaussians      /root/reference/gaussians.py:48-58
+//   order 1  gaussians.gaussian_derivative   /root/reference/gaussians.py:89-101
+//   order 2  gaussians.gaussian_derivative2  /root/reference/gaussians.py:103-116 (full Hessian)
+//   order 3  its derivative wrt the sample point (shape n,d,d,d,c: model_pn.py:654)
+// with  x = s - mu,  p = C x,  q = x.p,  g = exp(-q/2),  w_c = v_c g.
+//
+// Derivative outputs are symmetric in their derivative indices, so accumulators keep only the
+// distinct components (D=2: xx,xy,yy and xxx,xxy,xyy,yyy) and expand on store.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pigs {
+
+constexpr int ORD0 = 1, ORD1 = 2, ORD2 = 4, ORD3 = 8;
+
+template <int D> struct Sym {
+    static constexpr int NF = D * (D + 1) / 2;            // distinct 2nd-order components
+    static constexpr int N3 = D * (D + 1) * (D + 2) / 6;  // distinct 3rd-order components
+};
+
+template <typename T> __device__ __forceinline__ T exp_neg_half(T q);
+template <> __device__ __forceinline__ float exp_neg_half<float>(float q) {
+    // v_exp_f32 on a pre-scaled argument: exp(-q/2) = 2^(-q * log2(e)/2)
+    return __builtin_amdgcn_exp2f(q * -0.72134752044448170368f);
+}
+template <> __device__ __forceinline__ double exp_neg_half<double>(double q) { return exp(-0.5 * q); }
+
+template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Layout of the flat forward accumulator array for a compile-time order mask.
+template <int D, int C, int MASK> struct FwdLayout {
+    static constexpr int O0 = 0;
+    static constexpr int O1 = O0 + ((MASK & ORD0) ? C : 0);
+    static constexpr int O2 = O1 + ((MASK & ORD1) ? D * C : 0);
+    static constexpr int O3 = O2 + ((MASK & ORD2) ? Sym<D>::NF * C : 0);
+    static constexpr int N = O3 + ((MASK & ORD3) ? Sym<D>::N3 * C : 0);
+};
+
+// Pair geometry: x, p, g (and nothing else) for one (point, Gaussian).
+template <typename T, int D> struct Pair {
+    T x[D], p[D], g;
+    __device__ __forceinline__ void eval(const T* s, const T* mu, const T* con) {
+        if constexpr (D == 1) {
+            x[0] = s[0] - mu[0];
+            p[0] = con[0] * x[0];
+            g = exp_neg_half<T>(x[0] * p[0]);
+        } else {
+            x[0] = s[0] - mu[0];
+            x[1] = s[1] - mu[1];
+            p[0] = fma_<T>(con[1], x[1], con[0] * x[0]);
+            p[1] = fma_<T>(con[2], x[1], con[1] * x[0]);
+            g = exp_neg_half<T>(fma_<T>(x[1], p[1], x[0] * p[0]));
+        }
+    }
+};
+
+// acc += contributions of one Gaussian to the outputs selected by MASK at one sample point.
+// The order-1 accumulator holds +sum(p w); the sign is applied on store.
+template <typename T, int D, int C, int MASK>
+__device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, const T* con, const T* v) {
+    using L = FwdLayout<D, C, MASK>;
+    Pair<T, D> pr;
+    pr.eval(s, mu, con);
+    if constexpr (D == 1) {
+        const T p = pr.p[0];
+        T t2 = 0, t3 = 0;
+        if constexpr ((MASK & (ORD2 | ORD3)) != 0) t2 = fma_<T>(p, p, -con[0]);
+        if constexpr ((MASK & ORD3) != 0) t3 = p * (T(2) * con[0] - t2);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const T w = v[ch] * pr.g;
+            if constexpr ((MASK & ORD0) != 0) acc[L::O0 + ch] += w;
+            if constexpr ((MASK & ORD1) != 0) acc[L::O1 + ch] = fma_<T>(p, w, acc[L::O1 + ch]);
+            if constexpr ((MASK & ORD2) != 0) acc[L::O2 + ch] = fma_<T>(t2, w, acc[L::O2 + ch]);
+            if constexpr ((MASK & ORD3) != 0) acc[L::O3 + ch] = fma_<T>(t3, w, acc[L::O3 + ch]);
+        }
+    } else {
+        const T px = pr.p[0], py = pr.p[1];
+        T txx = 0, txy = 0, tyy = 0, t3[4] = {0, 0, 0, 0};
+        if constexpr ((MASK & (ORD2 | ORD3)) != 0) {
+            txx = fma_<T>(px, px, -con[0]);
+            tyy = fma_<T>(py, py, -con[2]);
+        }
+        if constexpr ((MASK & ORD2) != 0) txy = fma_<T>(px, py, -con[1]);
+        if constexpr ((MASK & ORD3) != 0) {
+            // C_ij p_k + C_ik p_j + C_jk p_i - p_i p_j p_k, written through t_ij = p_i p_j - C_ij
+            const T b2 = T(2) * con[1];
+            t3[0] = px * (T(2) * con[0] - txx);   // xxx = 3a px - px^3
+            t3[1] = fma_<T>(b2, px, -txx * py);   // xxy = 2b px + a py - px^2 py
+            t3[2] = fma_<T>(b2, py, -tyy * px);   // xyy = c px + 2b py - px py^2
+            t3[3] = py * (T(2) * con[2] - tyy);   // yyy = 3c py - py^3
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const T w = v[ch] * pr.g;
+            if constexpr ((MASK & ORD0) != 0) acc[L::O0 + ch] += w;
+            if constexpr ((MASK & ORD1) != 0) {
+                acc[L::O1 + 0 * C + ch] = fma_<T>(px, w, acc[L::O1 + 0 * C + ch]);
+                acc[L::O1 + 1 * C + ch] = fma_<T>(py, w, acc[L::O1 + 1 * C + ch]);
+            }
+            if constexpr ((MASK & ORD2) != 0) {
+                acc[L::O2 + 0 * C + ch] = fma_<T>(txx, w, acc[L::O2 + 0 * C + ch]);
+                acc[L::O2 + 1 * C + ch] = fma_<T>(txy, w, acc[L::O2 + 1 * C + ch]);
+                acc[L::O2 + 2 * C + ch] = fma_<T>(tyy, w, acc[L::O2 + 2 * C + ch]);
+            }
+            if constexpr ((MASK & ORD3) != 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[L::O3 + k * C + ch] = fma_<T>(t3[k], w, acc[L::O3 + k * C + ch]);
+            }
+        }
+    }
+}
+
+// Expand the symmetric accumulators into the reference layouts
+//   out0[M][c], out1[M][d][c], out2[M][d][d][c], out3[M][d][d][d][c]
+// for point m.  Null output pointers are skipped (the order was computed but not requested).
+template <typename T, int D, int C, int MASK>
+__device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict__ o0, T* __restrict__ o1,
+                                          T* __restrict__ o2, T* __restrict__ o3) {
+    using L = FwdLayout<D, C, MASK>;
+    if constexpr ((MASK & ORD0) != 0) {
+        if (o0) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) o0[m * C + ch] = acc[L::O0 + ch];
+        }
+    }
+    if constexpr ((MASK & ORD1) != 0) {
+        if (o1) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) o1[(m * D + i) * C + ch] = -acc[L::O1 + i * C + ch];
+        }
+    }
+    if constexpr ((MASK & ORD2) != 0) {
+        if (o2) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch)
+                        o2[((m * D + i) * D + j) * C + ch] = acc[L::O2 + (i + j) * C + ch];  // D<=2: sym index = i+j
+        }
+    }
+    if constexpr ((MASK & ORD3) != 0) {
+        if (o3) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+#pragma unroll
+                        for (int ch = 0; ch < C; ++ch)
+                            o3[(((m * D + i) * D + j) * D + k) * C + ch] = acc[L::O3 + (i + j + k) * C + ch];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward (VJP) of the selected outputs wrt (means, flat conics, values) for one pair.
+//
+//   L = sum_m sum_n g sum_c v_c F_c ,  F_c = G0_c - G1_ic p_i + H_ij,c t_ij + K_ijk,c poly3_ijk
+// with the incoming gradients symmetrised once per point (Gsym below).  With A = sum_c v_c F_c,
+// dA = grad_p A and E = explicit dA/dC:
+//   dL/dv_c   += g F_c
+//   dL/dmu_l  += g (A p_l - sum_i dA_i C_il)
+//   dL/dC_kl  += g (-A x_k x_l / 2 + dA_k x_l + E_kl)      (full matrix; flat = [00, 01+10, 11])
+// This is what torch.autograd gives through the reference functions
+// (test_derivatives.py:122-124, 208-220, 340-356).
+// ---------------------------------------------------------------------------------------------
+
+// Incoming gradients at one sample point, symmetrised over derivative indices.
+template <typename T, int D, int C, int MASK> struct Gsym {
+    T g0[C], g1[D][C], g2[Sym<D>::NF][C], g3[Sym<D>::N3][C];
+    // Null gradient pointers (an order inside the compiled mask whose output received no
+    // gradient) read as zero.
+    __device__ __forceinline__ void load(int64_t m, const T* __restrict__ G0, const T* __restrict__ G1,
+                                         const T* __restrict__ G2, const T* __restrict__ G3) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            if constexpr ((MASK & ORD0) != 0) g0[ch] = G0 ? G0[m * C + ch] : T(0);
+            if constexpr ((MASK & ORD1) != 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) g1[i][ch] = G1 ? G1[(m * D + i) * C + ch] : T(0);
+            }
+            if constexpr ((MASK & ORD2) != 0) {
+#pragma unroll
+                for (int k = 0; k < Sym<D>::NF; ++k) g2[k][ch] = 0;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) g2[i + j][ch] += G2 ? G2[((m * D + i) * D + j) * C + ch] : T(0);
+            }
+            if constexpr ((MASK & ORD3) != 0) {
+#pragma unroll
+                for (int k = 0; k < Sym<D>::N3; ++k) g3[k][ch] = 0;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j)
+#pragma unroll
+                        for (int k = 0; k < D; ++k)
+                            g3[i + j + k][ch] += G3 ? G3[(((m * D + i) * D + j) * D + k) * C + ch] : T(0);
+            }
+        }
+    }
+};
+
+// Flat backward accumulator: [g_means D][g_conics NF][g_values C]
+template <int D, int C> struct BwdLayout {
+    static constexpr int MU = 0;
+    static constexpr int CON = D;
+    static constexpr int VAL = D + Sym<D>::NF;
+    static constexpr int N = D + Sym<D>::NF + C;
+};
+
+template <typename T, int D, int C, int MASK>
+__device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, const T* con, const T* v,
+                                               const Gsym<T, D, C, MASK>& G) {
+    using L = BwdLayout<D, C>;
+    Pair<T, D> pr;
+    pr.eval(s, mu, con);
+    const T g = pr.g;
+    if constexpr (D == 1) {
+        const T p = pr.p[0], x = pr.x[0], a = con[0];
+        const T t2 = fma_<T>(p, p, -a);        // p^2 - a
+        const T t3 = p * (T(2) * a - t2);      // 3 a p - p^3
+        T A = 0, dA = 0, E = 0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            T F = 0, dF = 0, eF = 0;
+            if constexpr ((MASK & ORD0) != 0) F += G.g0[ch];
+            if constexpr ((MASK & ORD1) != 0) { F = fma_<T>(-G.g1[0][ch], p, F); dF -= G.g1[0][ch]; }
+            if constexpr ((MASK & ORD2) != 0) {
+                F = fma_<T>(G.g2[0][ch], t2, F);
+                dF = fma_<T>(T(2) * G.g2[0][ch], p, dF);
+                eF -= G.g2[0][ch];
+            }
+            if constexpr ((MASK & ORD3) != 0) {
+                F = fma_<T>(G.g3[0][ch], t3, F);
+                dF = fma_<T>(G.g3[0][ch], T(-3) * t2, dF);     // d/dp (3ap - p^3) = 3a - 3p^2
+                eF = fma_<T>(T(3) * G.g3[0][ch], p, eF);       // d/da (3ap) = 3p
+            }
+            acc[L::VAL + ch] = fma_<T>(g, F, acc[L::VAL + ch]);
+            A = fma_<T>(v[ch], F, A);
+            dA = fma_<T>(v[ch], dF, dA);
+            E = fma_<T>(v[ch], eF, E);
+        }
+        acc[L::MU] = fma_<T>(g, fma_<T>(A, p, -dA * a), acc[L::MU]);
+        acc[L::CON] = fma_<T>(g, fma_<T>(T(-0.5) * A * x, x, fma_<T>(dA, x, E)), acc[L::CON]);
+    } else {
+        const T px = pr.p[0], py = pr.p[1], dx = pr.x[0], dy = pr.x[1];
+        const T a = con[0], b = con[1], c = con[2];
+        const T txx = fma_<T>(px, px, -a), txy = fma_<T>(px, py, -b), tyy = fma_<T>(py, py, -c);
+        T A = 0, dAx = 0, dAy = 0, Exx = 0, Exy = 0, Eyy = 0;   // Exy holds E_01 + E_10
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            T F = 0, dFx = 0, dFy = 0, exx = 0, exy = 0, eyy = 0;
+            if constexpr ((MASK & ORD0) != 0) F += G.g0[ch];
+            if constexpr ((MASK & ORD1) != 0) {
+                F = fma_<T>(-G.g1[0][ch], px, F);
+                F = fma_<T>(-G.g1[1][ch], py, F);
+                dFx -= G.g1[0][ch];
+                dFy -= G.g1[1][ch];
+            }
+            if constexpr ((MASK & ORD2) != 0) {
+                const T hxx = G.g2[0][ch], hxy = G.g2[1][ch], hyy = G.g2[2][ch];
+                F = fma_<T>(hxx, txx, F);
+                F = fma_<T>(hxy, txy, F);
+                F = fma_<T>(hyy, tyy, F);
+                dFx = fma_<T>(T(2) * hxx, px, fma_<T>(hxy, py, dFx));
+                dFy = fma_<T>(T(2) * hyy, py, fma_<T>(hxy, px, dFy));
+                exx -= hxx;
+                exy -= hxy;
+                eyy -= hyy;
+            }
+            if constexpr ((MASK & ORD3) != 0) {
+                const T k0 = G.g3[0][ch], k1 = G.g3[1][ch], k2 = G.g3[2][ch], k3 = G.g3[3][ch];
+                // poly: xxx = 3a px - px^3 ; xxy = 2b px + a py - px^2 py ;
+                //       xyy = c px + 2b py - px py^2 ; yyy = 3c py - py^3
+                F = fma_<T>(k0, px * (T(2) * a - txx), F);
+                F = fma_<T>(k1, fma_<T>(T(2) * b, px, -txx * py), F);
+                F = fma_<T>(k2, fma_<T>(T(2) * b, py, -tyy * px), F);
+                F = fma_<T>(k3, py * (T(2) * c - tyy), F);
+                // d/dpx
+                dFx = fma_<T>(k0, T(-3) * txx, dFx);
+                dFx = fma_<T>(k1, T(-2) * txy, dFx);
+                dFx = fma_<T>(k2, -tyy, dFx);
+                // d/dpy
+                dFy = fma_<T>(k1, -txx, dFy);
+                dFy = fma_<T>(k2, T(-2) * txy, dFy);
+                dFy = fma_<T>(k3, T(-3) * tyy, dFy);
+                // explicit d/da, d/db (flat: both off-diagonal entries), d/dc
+                exx = fma_<T>(T(3) * k0, px, fma_<T>(k1, py, exx));
+                exy = fma_<T>(T(2) * k1, px, fma_<T>(T(2) * k2, py, exy));
+                eyy = fma_<T>(T(3) * k3, py, fma_<T>(k2, px, eyy));
+            }
+            acc[L::VAL + ch] = fma_<T>(g, F, acc[L::VAL + ch]);
+            A = fma_<T>(v[ch], F, A);
+            dAx = fma_<T>(v[ch], dFx, dAx);
+            dAy = fma_<T>(v[ch], dFy, dAy);
+            Exx = fma_<T>(v[ch], exx, Exx);
+            Exy = fma_<T>(v[ch], exy, Exy);
+            Eyy = fma_<T>(v[ch], eyy, Eyy);
+        }
+        // means: g (A p_l - (dA . C)_l)
+        acc[L::MU + 0] = fma_<T>(g, fma_<T>(A, px, -fma_<T>(dAx, a, dAy * b)), acc[L::MU + 0]);
+        acc[L::MU + 1] = fma_<T>(g, fma_<T>(A, py, -fma_<T>(dAx, b, dAy * c)), acc[L::MU + 1]);
+        // flat conic: [G00, G01 + G10, G11]
+        const T hA = T(-0.5) * A;
+        acc[L::CON + 0] = fma_<T>(g, fma_<T>(hA * dx, dx, fma_<T>(dAx, dx, Exx)), acc[L::CON + 0]);
+        acc[L::CON + 1] = fma_<T>(g, fma_<T>(-A * dx, dy, fma_<T>(dAx, dy, fma_<T>(dAy, dx, Exy))), acc[L::CON + 1]);
+        acc[L::CON + 2] = fma_<T>(g, fma_<T>(hA * dy, dy, fma_<T>(dAy, dy, Eyy)), acc[L::CON + 2]);
+    }
+}
+
+}  // namespace pigs

@@ -1,0 +1,243 @@
+"""Host side of the sampler: the reference's ``GaussianSampler`` operator surface on MI355X.
+
+Mirrors the Python-visible interface of the reference's native extension
+(``from diff_gaussian_sampling import GaussianSampler``), known from its call sites:
+
+* ``GaussianSampler(flag)``                       model_pn.py:423 (False), tests (True)
+* ``preprocess(means, values, covariances, conics, samples)``
+                                                  model_pn.py:648,768,784; test_gaussian_sampling.py:56;
+                                                  test_derivatives.py:82; test_1d.py:30
+* ``sample_gaussians()            -> [M, c]``      model_pn.py:650
+* ``sample_gaussians_derivative() -> [M, d, c]``   model_pn.py:651
+* ``sample_gaussians_laplacian()  -> [M, d, d, c]`` (the full Hessian) model_pn.py:652
+* ``sample_gaussians_third_derivative() -> [M, d, d, d, c]``  model_pn.py:654
+
+Outputs are differentiable wrt the ``means``, ``values`` and ``conics`` passed to the preceding
+``preprocess`` (test_derivatives.py:123, 214-215, 349-352), also after later ``preprocess`` calls
+(model_pn.py:766-788 then main_pn.py:220): every autograd node owns the tensors it needs.
+
+All arithmetic runs in the HIP library behind the C ABI of include/pigs_amd.h; there is no CPU
+or PyTorch fallback -- CPU tensors are rejected.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_ORDER_NAMES = ("sample_gaussians", "sample_gaussians_derivative", "sample_gaussians_laplacian",
+                "sample_gaussians_third_derivative")
+_DTYPES = {torch.float32: _lib.PIGS_F32, torch.float64: _lib.PIGS_F64}
+
+
+def _out_shape(order, M, d, c):
+    return (M,) + (d,) * order + (c,)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _mask_orders(mask):
+    return [k for k in range(4) if mask >> k & 1]
+
+
+def forward_raw(means, values, conics, samples, mask):
+    """Launch the forward for the orders in ``mask`` on contiguous device tensors.
+    Returns a list of 4 entries (tensor or None)."""
+    lib = _lib.load()
+    N, d = means.shape
+    c = values.shape[1]
+    M = samples.shape[0]
+    outs = [None] * 4
+    for k in _mask_orders(mask):
+        outs[k] = torch.empty(_out_shape(k, M, d, c), dtype=means.dtype, device=means.device)
+    if M > 0:
+        with torch.cuda.device(means.device):
+            rc = lib.pigs_sample_forward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
+                                         _ptr(values), _ptr(samples), _ptr(outs[0]), _ptr(outs[1]),
+                                         _ptr(outs[2]), _ptr(outs[3]), _stream(means.device))
+        _lib.check(rc, "pigs_sample_forward")
+    return outs
+
+
+def backward_raw(means, values, conics, samples, gouts, mask):
+    """Launch the backward; ``gouts`` has 4 entries (contiguous tensor or None), ``mask`` marks the
+    non-None ones.  Returns (g_means, g_values, g_conics)."""
+    lib = _lib.load()
+    N, d = means.shape
+    c = values.shape[1]
+    M = samples.shape[0]
+    g_means = torch.empty_like(means)
+    g_values = torch.empty_like(values)
+    g_conics = torch.empty_like(conics)
+    if N > 0:
+        with torch.cuda.device(means.device):
+            rc = lib.pigs_sample_backward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
+                                          _ptr(values), _ptr(samples), _ptr(gouts[0]), _ptr(gouts[1]),
+                                          _ptr(gouts[2]), _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics),
+                                          _ptr(g_values), _stream(means.device))
+        _lib.check(rc, "pigs_sample_backward")
+    return g_means, g_values, g_conics
+
+
+class _SampleFunction(torch.autograd.Function):
+    """One fused launch producing the outputs of every order in ``mask``; its backward is one
+    fused launch over the outputs that received a gradient."""
+
+    @staticmethod
+    def forward(ctx, means, values, conics, samples, mask, debug):
+        outs = forward_raw(means, values, conics, samples, mask)
+        if debug:
+            torch.cuda.synchronize(means.device)
+        ctx.save_for_backward(means, values, conics, samples)
+        ctx.mask = mask
+        ctx.debug = debug
+        ctx.set_materialize_grads(False)
+        return tuple(outs[k] for k in _mask_orders(mask))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grad_outputs):
+        means, values, conics, samples = ctx.saved_tensors
+        gouts = [None] * 4
+        mask = 0
+        for k, g in zip(_mask_orders(ctx.mask), grad_outputs):
+            if g is not None:
+                gouts[k] = g.contiguous()
+                mask |= 1 << k
+        if mask == 0:
+            return None, None, None, None, None, None
+        g_means, g_values, g_conics = backward_raw(means, values, conics, samples, gouts, mask)
+        if ctx.debug:
+            torch.cuda.synchronize(means.device)
+        return g_means, g_values, g_conics, None, None, None
+
+
+class GaussianSampler:
+    """MI355X-native replacement of ``diff_gaussian_sampling.GaussianSampler``.
+
+    ``flag`` is the single positional bool of the reference constructor (True in its tests,
+    False in model_pn.py:423; meaning not visible in the reference).  Here it is a debug switch:
+    when set, every launch is followed by a device synchronise so that errors surface at the call.
+
+    ``fuse`` (extension, keyword only) controls how many derivative orders one launch computes:
+    ``"auto"`` -- the first ``sample_*`` call after a ``preprocess`` computes orders 0..2 in one
+    launch when the problem is small enough to be launch-bound (M <= 65536), otherwise only the
+    order asked for; ``"all"`` / ``"none"`` force either behaviour.  :meth:`sample` is the
+    explicit fused entry point.
+    """
+
+    FUSE_AUTO_MAX_POINTS = 1 << 16
+
+    def __init__(self, flag=False, *, fuse="auto"):
+        if fuse not in ("auto", "all", "none"):
+            raise ValueError("fuse must be 'auto', 'all' or 'none'")
+        self.debug = bool(flag)
+        self.fuse = fuse
+        self._inputs = None
+        self._cache = {}
+        _lib.load()  # fail at construction, not at first use, if the HIP library is missing
+
+    # ------------------------------------------------------------------ preprocess
+    def preprocess(self, means, values, covariances, conics, samples):
+        """Bind the Gaussians and the sample points for the following ``sample_*`` calls.
+
+        means [N,d]; values [N,c] (or [N]); covariances and conics flat [N, d(d+1)/2]
+        (d=1: anything with N elements, e.g. [N,1] or [N,1,1]); samples [M,d] (d=1: also [M]).
+        ``covariances`` does not enter the sampled values (the reference's dense twin,
+        gaussians.py:48-58, never reads it); it is accepted for interface parity.
+        """
+        if means.dim() != 2:
+            raise ValueError(f"means must be [N, d], got {tuple(means.shape)}")
+        N, d = means.shape
+        if d not in (1, 2):
+            raise NotImplementedError(f"d = {d} is not supported (d in {{1, 2}})")
+        nf = d * (d + 1) // 2
+        for name, t in (("means", means), ("values", values), ("conics", conics), ("samples", samples)):
+            if not isinstance(t, torch.Tensor):
+                raise TypeError(f"{name} must be a torch.Tensor")
+            if not t.is_cuda:
+                raise RuntimeError(f"{name} is on {t.device}: GaussianSampler runs on the GPU only "
+                                   "(no CPU fallback)")
+            if t.device != means.device:
+                raise RuntimeError(f"{name} is on {t.device}, means on {means.device}")
+            if t.dtype != means.dtype:
+                raise TypeError(f"{name} has dtype {t.dtype}, means {means.dtype}")
+        if means.dtype not in _DTYPES:
+            raise TypeError(f"dtype {means.dtype} is not supported (float32 / float64)")
+        if values.dim() == 1:
+            values = values.reshape(N, 1)
+        if values.dim() != 2 or values.shape[0] != N:
+            raise ValueError(f"values must be [N, c], got {tuple(values.shape)}")
+        c = values.shape[1]
+        if not 1 <= c <= 4:
+            raise NotImplementedError(f"c = {c} channels is not supported (1..4)")
+        if conics.numel() != N * nf:
+            raise ValueError(f"conics must hold N*{nf} elements (flat upper triangle), got {tuple(conics.shape)}")
+        conics = conics.reshape(N, nf)
+        if covariances is not None and isinstance(covariances, torch.Tensor) and covariances.numel() != N * nf:
+            raise ValueError(f"covariances must hold N*{nf} elements, got {tuple(covariances.shape)}")
+        if samples.dim() == 1 and d == 1:
+            samples = samples.reshape(-1, 1)
+        if samples.dim() != 2 or samples.shape[1] != d:
+            raise ValueError(f"samples must be [M, {d}], got {tuple(samples.shape)}")
+        # no gradient flows to the sample points (the reference requests none from the sampler:
+        # test_derivatives.py:123 asks for (means, values, conics) only)
+        self._inputs = (means.contiguous(), values.contiguous(), conics.contiguous(),
+                        samples.detach().contiguous())
+        self._cache = {}
+
+    # ------------------------------------------------------------------ sampling
+    def _require_inputs(self):
+        if self._inputs is None:
+            raise RuntimeError("preprocess() must be called before sampling")
+        return self._inputs
+
+    def _compute(self, mask):
+        means, values, conics, samples = self._require_inputs()
+        outs = _SampleFunction.apply(means, values, conics, samples, mask, self.debug)
+        for k, o in zip(_mask_orders(mask), outs):
+            self._cache[k] = o
+
+    def _get(self, order):
+        if order not in self._cache:
+            means, _, _, samples = self._require_inputs()
+            mask = 1 << order
+            if order <= 2 and (self.fuse == "all" or (
+                    self.fuse == "auto" and samples.shape[0] <= self.FUSE_AUTO_MAX_POINTS)):
+                mask = 7 & ~sum(1 << k for k in self._cache)
+                mask |= 1 << order
+            self._compute(mask)
+        return self._cache[order]
+
+    def sample(self, orders=(0, 1, 2)):
+        """Fused entry point: one launch for all ``orders`` (extension of the reference API).
+        Returns a tuple of outputs in the order given."""
+        orders = tuple(int(o) for o in orders)
+        if any(o < 0 or o > 3 for o in orders):
+            raise ValueError("orders must be in 0..3")
+        mask = sum(1 << o for o in set(orders) if o not in self._cache)
+        if mask:
+            self._compute(mask)
+        return tuple(self._cache[o] for o in orders)
+
+    def sample_gaussians(self):
+        """u [M, c]"""
+        return self._get(0)
+
+    def sample_gaussians_derivative(self):
+        """du/dx [M, d, c]"""
+        return self._get(1)
+
+    def sample_gaussians_laplacian(self):
+        """full Hessian [M, d, d, c] (the reference's name is a misnomer: model_pn.py:614,652)"""
+        return self._get(2)
+
+    def sample_gaussians_third_derivative(self):
+        """third derivatives [M, d, d, d, c]"""
+        return self._get(3)

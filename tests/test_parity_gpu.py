@@ -1,0 +1,224 @@
+"""GPU parity: the HIP path (through the GaussianSampler surface -> C ABI) against the fixtures
+produced by the reference and against the CPU oracle on the same seeded inputs.
+
+Bar (north_star): forward values, derivatives and parameter gradients within 1e-5 relative
+(max-abs error over the tensor / max-abs of the expected tensor) in float32; 1e-11 in float64.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_files
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+F64_TOL = 1e-11
+D12 = [f for f in golden_files() if "d3" not in f]
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def dev(a, dtype):
+    return torch.as_tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def Sampler(hip_lib):
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from diff_gaussian_sampling import GaussianSampler
+    return GaussianSampler
+
+
+def load_case(name, dtype):
+    z = np.load(os.path.join(GOLDEN, name))
+    t = {k: dev(z[k], dtype) for k in ("means", "values", "covariances", "conics", "samples")}
+    return z, t
+
+
+@pytest.mark.parametrize("fuse", ["none", "all"])
+@pytest.mark.parametrize("name", D12)
+def test_forward_f64_matches_reference(Sampler, name, fuse):
+    z, t = load_case(name, torch.float64)
+    s = Sampler(True, fuse=fuse)
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+    outs = (s.sample_gaussians(), s.sample_gaussians_derivative(), s.sample_gaussians_laplacian(),
+            s.sample_gaussians_third_derivative())
+    for o, out in enumerate(outs):
+        assert tuple(out.shape) == z[f"out{o}_f64"].shape
+        assert rel(out, z[f"out{o}_f64"]) < F64_TOL, (name, o)
+
+
+@pytest.mark.parametrize("fuse", ["none", "all"])
+@pytest.mark.parametrize("name", D12)
+def test_forward_f32_matches_reference(Sampler, name, fuse):
+    z, t = load_case(name, torch.float32)
+    s = Sampler(True, fuse=fuse)
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+    outs = (s.sample_gaussians(), s.sample_gaussians_derivative(), s.sample_gaussians_laplacian(),
+            s.sample_gaussians_third_derivative())
+    # expected: float64 oracle on the float32-rounded inputs (isolates the kernel's arithmetic) ...
+    exp = c_oracle.forward(*(t[k].cpu().double().numpy() for k in ("means", "conics", "values", "samples")),
+                           orders=(0, 1, 2, 3))
+    for o, out in enumerate(outs):
+        assert out.dtype == torch.float32
+        assert rel(out, exp[o]) < F32_TOL, (name, o)
+        # ... and the reference's own float64 outputs on the unrounded inputs
+        assert rel(out, z[f"out{o}_f64"]) < 2 * F32_TOL, (name, o)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, F64_TOL), (torch.float32, F32_TOL)])
+@pytest.mark.parametrize("name", D12)
+def test_backward_per_order_matches_reference_autograd(Sampler, name, dtype, tol):
+    """test_derivatives.py:123,214-215,349-352: grads of each output wrt (means, values, conics)."""
+    z, t = load_case(name, dtype)
+    for k in ("means", "values", "conics"):
+        t[k].requires_grad_(True)
+    s = Sampler(True, fuse="none")
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+    getters = (s.sample_gaussians, s.sample_gaussians_derivative, s.sample_gaussians_laplacian,
+               s.sample_gaussians_third_derivative)
+    for o, get in enumerate(getters):
+        out = get()
+        r = dev(z[f"r{o}"], dtype)
+        gm, gv, gc = torch.autograd.grad((out * r).sum(), (t["means"], t["values"], t["conics"]))
+        if dtype == torch.float32:
+            em, ec, ev = c_oracle.backward(*(t[k].detach().cpu().double().numpy()
+                                             for k in ("means", "conics", "values", "samples")),
+                                           {o: r.cpu().double().numpy()})
+        else:
+            em, ev, ec = z[f"gmeans{o}_f64"], z[f"gvalues{o}_f64"], z[f"gconics{o}_f64"]
+        assert rel(gm, em) < tol, (name, o, "means")
+        assert rel(gv, ev) < tol, (name, o, "values")
+        assert rel(gc, ec) < tol, (name, o, "conics")
+        if dtype == torch.float32:
+            assert rel(gm, z[f"gmeans{o}_f64"]) < 3 * tol
+            assert rel(gc, z[f"gconics{o}_f64"]) < 3 * tol
+
+
+@pytest.mark.parametrize("name", ["random_d2_c2.npz", "ref_test_derivatives.npz", "random_d1_c2.npz"])
+def test_backward_fused_after_second_preprocess(Sampler, name):
+    """model_pn.py:766-788: outputs stay differentiable after a later preprocess() rebinds the
+    sampler; one loss over orders 0..2 (test_no_mlp.py:127-146) gives one fused backward."""
+    z, t = load_case(name, torch.float64)
+    for k in ("means", "values", "conics"):
+        t[k].requires_grad_(True)
+    s = Sampler(False, fuse="all")
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+    u, ux, uxx = s.sample_gaussians(), s.sample_gaussians_derivative(), s.sample_gaussians_laplacian()
+    # rebind to something else entirely before backward
+    s.preprocess(t["means"][:3].detach() + 1, t["values"][:3].detach(), None, t["conics"][:3].detach(),
+                 t["samples"][:5])
+    _ = s.sample_gaussians()
+    loss = sum((o * dev(z[f"r{k}"], torch.float64)).sum() for k, o in enumerate((u, ux, uxx)))
+    loss.backward()
+    for key, g in (("gmeans", t["means"].grad), ("gvalues", t["values"].grad), ("gconics", t["conics"].grad)):
+        exp = sum(z[f"{key}{k}_f64"] for k in range(3))
+        assert rel(g, exp) < F64_TOL, (name, key)
+
+
+def test_no_grad_and_sample_api(Sampler):
+    z, t = load_case("random_d2_c1.npz", torch.float32)
+    s = Sampler(False)
+    with torch.no_grad():
+        s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+        u, ux, uxx, uxxx = s.sample((0, 1, 2, 3))
+    assert not u.requires_grad
+    for o, out in enumerate((u, ux, uxx, uxxx)):
+        assert rel(out, z[f"out{o}_f64"]) < 2 * F32_TOL
+    # derivative outputs are symmetric in their derivative indices
+    assert torch.equal(uxx[:, 0, 1], uxx[:, 1, 0])
+    assert torch.equal(uxxx[:, 0, 0, 1], uxxx[:, 1, 0, 0])
+
+
+def test_1d_call_shapes(Sampler):
+    """test_1d.py:27-30: samples given as a 1-D tensor, conics as [N,1]."""
+    z, t = load_case("ref_test_1d.npz", torch.float32)
+    s = Sampler(True)
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"].reshape(-1))
+    assert tuple(s.sample_gaussians().shape) == (200, 1)
+    assert tuple(s.sample_gaussians_derivative().shape) == (200, 1, 1)
+    assert tuple(s.sample_gaussians_laplacian().shape) == (200, 1, 1, 1)
+    assert rel(s.sample_gaussians_laplacian(), z["out2_f64"]) < 2 * F32_TOL
+
+
+def test_masked_noncontiguous_inputs(Sampler):
+    """model_pn.py:769: inputs arrive as boolean-mask selections / non-contiguous views."""
+    z, t = load_case("random_d2_c1.npz", torch.float64)
+    N = t["means"].shape[0]
+    mask = torch.ones(N, dtype=torch.bool, device="cuda")
+    means_nc = torch.stack((t["means"], t["means"]), dim=2)[:, :, 0]     # non-contiguous view
+    assert not means_nc.is_contiguous()
+    s = Sampler(True)
+    s.preprocess(means_nc[mask], t["values"][mask], t["covariances"][mask], t["conics"][mask], t["samples"])
+    assert rel(s.sample_gaussians(), z["out0_f64"]) < F64_TOL
+
+
+def test_empty_inputs(Sampler):
+    s = Sampler(True)
+    e = lambda *sh: torch.zeros(*sh, device="cuda")
+    s.preprocess(e(0, 2), e(0, 1), e(0, 3), e(0, 3), torch.rand(7, 2, device="cuda"))
+    assert tuple(s.sample_gaussians().shape) == (7, 1) and not s.sample_gaussians().any()
+    assert not s.sample_gaussians_laplacian().any()
+    s.preprocess(torch.rand(5, 2, device="cuda"), e(5, 1) + 1, e(5, 3) + 1, e(5, 3) + 1, e(0, 2))
+    assert tuple(s.sample_gaussians_derivative().shape) == (0, 2, 1)
+    means = torch.rand(5, 2, device="cuda", requires_grad=True)
+    s.preprocess(means, e(5, 1) + 1, None, e(5, 3) + 1, e(0, 2))
+    s.sample_gaussians().sum().backward()
+    assert not means.grad.any()
+
+
+@pytest.mark.parametrize("N,M,d,c", [(1, 1, 2, 1), (63, 65, 2, 1), (257, 1000, 2, 2), (1000, 1024, 2, 1),
+                                      (5, 4097, 1, 1), (300, 129, 1, 3), (129, 70, 2, 4)])
+def test_ragged_sizes_against_oracle(Sampler, N, M, d, c):
+    rng = np.random.default_rng(N * 7 + M)
+    means = rng.uniform(-1, 1, (N, d))
+    nf = d * (d + 1) // 2
+    if d == 2:
+        s0 = np.exp(rng.normal(-3, 0.5, (N, 2)))
+        tau = np.tanh(rng.normal(0, 0.7, N)) * np.sqrt(s0[:, 0] * s0[:, 1])
+        det = s0[:, 0] * s0[:, 1] - tau ** 2
+        con = np.stack((s0[:, 1] / det, -tau / det, s0[:, 0] / det), -1)
+    else:
+        con = 1.0 / np.exp(rng.normal(-4, 0.5, (N, 1)))
+    values = rng.uniform(-1, 1, (N, c))
+    samples = rng.uniform(-1.1, 1.1, (M, d))
+    t = [dev(a, torch.float32) for a in (means, values, con, samples)]
+    for x in t[:3]:
+        x.requires_grad_(True)
+    s = Sampler(True, fuse="all")
+    s.preprocess(t[0], t[1], None, t[2], t[3])
+    outs = s.sample((0, 1, 2, 3))
+    args = [x.detach().cpu().double().numpy() for x in (t[0], t[2], t[1], t[3])]
+    exp = c_oracle.forward(*args, orders=(0, 1, 2, 3))
+    rs = {}
+    loss = 0
+    for o, out in enumerate(outs):
+        assert rel(out, exp[o]) < F32_TOL, (o,)
+        rs[o] = rng.uniform(-1, 1, exp[o].shape)
+        loss = loss + (out * dev(rs[o], torch.float32)).sum()
+    loss.backward()
+    em, ec, ev = c_oracle.backward(*args, {o: dev(r, torch.float32).cpu().double().numpy() for o, r in rs.items()})
+    assert rel(t[0].grad, em) < F32_TOL
+    assert rel(t[1].grad, ev) < F32_TOL
+    assert rel(t[2].grad, ec) < F32_TOL
+
+
+def test_config1_1d_256x4096(Sampler):
+    """BASELINE.json configs[0]: 1-D, 256 Gaussians x 4096 points."""
+    from pigs_amd import synthetic
+    gs, pts = synthetic.CONFIGS["c1"]()
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    s = Sampler(True)
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts.float().cuda())
+    outs = s.sample((0, 1, 2))
+    exp = c_oracle.forward(t["means"].cpu().double().numpy(), t["conics"].cpu().double().numpy(),
+                           t["values"].cpu().double().numpy(), pts.float().double().numpy(), orders=(0, 1, 2))
+    for o, out in enumerate(outs):
+        assert rel(out, exp[o]) < F32_TOL
