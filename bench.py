@@ -39,16 +39,28 @@ def parse():
     ap.add_argument("--kappa", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--backend", default="auto", choices=["auto", "dense", "binned"])
     return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may actually use: affinity, capped by the cgroup CPU quota and by the
+    GPU box's per-GPU share (16)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, 16))
 
 
 def cpu_baseline(gs, pts, budget_pairs=1.3e8):
     """The reference's dense PyTorch algorithm (oracle/dense_torch.py) on the host cores, on a
     bounded slice of the same workload; linear in M, so points/s extrapolates."""
     from oracle import dense_torch
-    cores = os.cpu_count() or 1
-    if hasattr(os, "sched_getaffinity"):
-        cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
     N = gs["means"].shape[0]
     m = int(max(256, min(pts.shape[0], budget_pairs // N)))
@@ -100,7 +112,7 @@ def main():
     N, M = gs["means"].shape[0], pts.shape[0]
     t = {k: v.float().to(dev) for k, v in gs.items()}
     pts_d = pts.float().to(dev)
-    sampler = GaussianSampler(False, fuse="all")
+    sampler = GaussianSampler(False, fuse="all", backend=a.backend)
 
     def step():
         sampler.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
@@ -131,11 +143,12 @@ def main():
     means, values, conics, samples = sampler._inputs
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.no_grad():
-        S.forward_raw(means, values, conics, samples, 7)
+        plan = sampler._plan
+        S.forward_raw(means, values, conics, samples, 7, plan)
         torch.cuda.synchronize(dev)
         e0.record()
         for _ in range(a.steps):
-            S.forward_raw(means, values, conics, samples, 7)
+            S.forward_raw(means, values, conics, samples, 7, plan)
         e1.record()
         torch.cuda.synchronize(dev)
     kernel_s = e0.elapsed_time(e1) / a.steps * 1e-3
@@ -143,9 +156,10 @@ def main():
     achieved = algo_bytes / kernel_s
     roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": None,
-                "kernel": "dense_forward_kernel<float,2,1,7>", "kernel_ms": kernel_s * 1e3,
-                "algorithmic_bytes": algo_bytes,
-                "valu_frac_dense_pairs": N * M / kernel_s / VALU_PAIR_PEAK}
+                "kernel": ("binned_forward_kernel<1,7>" if plan is not None else "dense_forward_kernel<float,2,1,7,4>"),
+                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": algo_bytes}
+    if plan is None:
+        roofline["valu_frac_dense_pairs"] = N * M / kernel_s / VALU_PAIR_PEAK
 
     # ---------------- fwd + bwd step (second half of BASELINE.json's metric) ----------------
     fwd_bwd = None
@@ -181,7 +195,7 @@ def main():
         "dtype": "f32", "data": "synthetic (seeded lattice Gaussians, regular sample grid)",
         "config": {"workload": f"{a.workload}: {N} Gaussians x {res}x{res} grid per GPU, d=2, c=1, "
                                f"kappa={a.kappa}, orders 0-2", "gaussians": N, "points_per_gpu": M,
-                   "kappa": a.kappa, "path": "dense", "step": "preprocess + fused forward (orders 0..2)"},
+                   "kappa": a.kappa, "path": "binned" if sampler._plan is not None else "dense", "step": "preprocess + fused forward (orders 0..2)"},
         "roofline": roofline, "fwd_bwd": fwd_bwd,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

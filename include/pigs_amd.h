@@ -66,6 +66,32 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
                          const void* gout0, const void* gout1, const void* gout2, const void* gout3,
                          void* g_means, void* g_conics, void* g_values, void* stream);
 
+/*
+ * Binned ("plan") path -- float32, d = 2, c <= 3.  preprocess() builds a plan in a caller-owned
+ * device workspace: Gaussians binned by centre into a multi-level cell grid (packed, sorted
+ * 32-byte records), sample points sorted into 64-point cells.  The sampling entry points then
+ * evaluate, for every point, only the Gaussians whose q <= q_max ellipse reaches the point's
+ * cell (dropped terms are below exp(-q_max/2) of a term's scale; q_max = 36 -> 1.5e-8).
+ * The workspace is opaque, position independent device memory of pigs_plan_workspace_bytes()
+ * bytes (256-byte aligned); the same (N, M, c, q_max) must be passed to every call on it.
+ * pigs_plan_backward uses scratch inside the workspace: calls sharing a workspace must be
+ * stream ordered.
+ */
+size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsupported sizes */
+
+int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
+                    const void* means, const void* conics, const void* values, const void* samples,
+                    void* stream);
+
+int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
+                      int orders_mask, const void* samples,
+                      void* out0, void* out1, void* out2, void* out3, void* stream);
+
+int pigs_plan_backward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
+                       int orders_mask, const void* samples,
+                       const void* gout0, const void* gout1, const void* gout2, const void* gout3,
+                       void* g_means, void* g_conics, void* g_values, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,11 @@ SIGNATURES = {
     "pigs_status_string": (ctypes.c_char_p, [_i]),
     "pigs_sample_forward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp]),
     "pigs_sample_backward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp] * 3 + [_vp]),
+    "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
+    "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float] + [_vp] * 4 + [_vp]),
+    "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i, _vp] + [_vp] * 4 + [_vp]),
+    "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i, _vp] + [_vp] * 4
+                           + [_vp] * 3 + [_vp]),
 }
 
 _lib = None

@@ -149,6 +149,7 @@ static int launch_dense_forward(const SampleArgs& a, hipStream_t stream) {
     const int64_t blocks = (a.M + 63) / 64;
     if (blocks == 0 ) return PIGS_OK;
     if (blocks > 0x7fffffffLL) return PIGS_ERR_INVALID;
+    clear_hip_error();
     const T* means = (const T*)a.means; const T* conics = (const T*)a.conics;
     const T* values = (const T*)a.values; const T* samples = (const T*)a.samples;
     T* o0 = (T*)a.out[0]; T* o1 = (T*)a.out[1]; T* o2 = (T*)a.out[2]; T* o3 = (T*)a.out[3];
@@ -159,14 +160,14 @@ static int launch_dense_forward(const SampleArgs& a, hipStream_t stream) {
       if (blocks < 1024 && a.N >= 64) {
         hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream,
                            a.N, a.M, means, conics, values, samples, o0, o1, o2, o3);
-        return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH;
+        return launch_status();
       }
     }
     {
         hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 4>), dim3((unsigned)blocks), dim3(256), 0, stream,
                            a.N, a.M, means, conics, values, samples, o0, o1, o2, o3);
     }
-    return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH;
+    return launch_status();
 }
 
 template <typename T, int D, int C, int MASK>
@@ -175,6 +176,7 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     const int64_t gblocks = (a.N + 63) / 64;
     if (gblocks == 0) return PIGS_OK;
     if (gblocks > 0x7fffffffLL) return PIGS_ERR_INVALID;
+    clear_hip_error();
     T* gm = (T*)a.g_means; T* gc = (T*)a.g_conics; T* gv = (T*)a.g_values;
     if (a.M == 0) {
         if (hipMemsetAsync(gm, 0, sizeof(T) * a.N * D, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
@@ -198,7 +200,7 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
                        0, stream, a.N, a.M, (const T*)a.means, (const T*)a.conics, (const T*)a.values,
                        (const T*)a.samples, (const T*)a.gout[0], (const T*)a.gout[1], (const T*)a.gout[2],
                        (const T*)a.gout[3], gm, gc, gv);
-    return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH;
+    return launch_status();
 }
 
 // Smallest compiled order mask that covers the request.  Compiled: single orders, 0..2 and 0..3.

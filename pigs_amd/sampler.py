@@ -46,9 +46,35 @@ def _mask_orders(mask):
     return [k for k in range(4) if mask >> k & 1]
 
 
-def forward_raw(means, values, conics, samples, mask):
-    """Launch the forward for the orders in ``mask`` on contiguous device tensors.
-    Returns a list of 4 entries (tensor or None)."""
+class Plan:
+    """The binned structure built by ``preprocess`` (C ABI: pigs_plan_*): an opaque device
+    workspace plus the scalars every call on it must repeat.  Immutable once built; autograd
+    nodes keep a reference, so later ``preprocess`` calls never disturb a pending backward."""
+
+    __slots__ = ("workspace", "N", "M", "c", "q_max")
+
+    def __init__(self, means, values, conics, samples, q_max):
+        lib = _lib.load()
+        self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
+        nbytes = lib.pigs_plan_workspace_bytes(self.N, self.M, self.c)
+        if nbytes == 0:
+            raise _lib.PigsError(f"binned path does not support N={self.N} M={self.M} c={self.c}")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
+        with torch.cuda.device(means.device):
+            rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, self.N, self.M, self.c, self.q_max,
+                                     _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
+                                     _stream(means.device))
+        _lib.check(rc, "pigs_plan_build")
+
+    @staticmethod
+    def supported(means, values, samples):
+        return (means.dtype == torch.float32 and means.shape[1] == 2 and 1 <= values.shape[1] <= 3
+                and means.shape[0] >= 1 and samples.shape[0] >= 1)
+
+
+def forward_raw(means, values, conics, samples, mask, plan=None):
+    """Launch the forward for the orders in ``mask`` on contiguous device tensors (through the
+    plan when given, else dense).  Returns a list of 4 entries (tensor or None)."""
     lib = _lib.load()
     N, d = means.shape
     c = values.shape[1]
@@ -58,14 +84,20 @@ def forward_raw(means, values, conics, samples, mask):
         outs[k] = torch.empty(_out_shape(k, M, d, c), dtype=means.dtype, device=means.device)
     if M > 0:
         with torch.cuda.device(means.device):
-            rc = lib.pigs_sample_forward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
-                                         _ptr(values), _ptr(samples), _ptr(outs[0]), _ptr(outs[1]),
-                                         _ptr(outs[2]), _ptr(outs[3]), _stream(means.device))
-        _lib.check(rc, "pigs_sample_forward")
+            if plan is not None:
+                rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
+                                           _ptr(samples), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                           _ptr(outs[3]), _stream(means.device))
+                _lib.check(rc, "pigs_plan_forward")
+            else:
+                rc = lib.pigs_sample_forward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
+                                             _ptr(values), _ptr(samples), _ptr(outs[0]), _ptr(outs[1]),
+                                             _ptr(outs[2]), _ptr(outs[3]), _stream(means.device))
+                _lib.check(rc, "pigs_sample_forward")
     return outs
 
 
-def backward_raw(means, values, conics, samples, gouts, mask):
+def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
     """Launch the backward; ``gouts`` has 4 entries (contiguous tensor or None), ``mask`` marks the
     non-None ones.  Returns (g_means, g_values, g_conics)."""
     lib = _lib.load()
@@ -77,11 +109,18 @@ def backward_raw(means, values, conics, samples, gouts, mask):
     g_conics = torch.empty_like(conics)
     if N > 0:
         with torch.cuda.device(means.device):
-            rc = lib.pigs_sample_backward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
-                                          _ptr(values), _ptr(samples), _ptr(gouts[0]), _ptr(gouts[1]),
-                                          _ptr(gouts[2]), _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics),
-                                          _ptr(g_values), _stream(means.device))
-        _lib.check(rc, "pigs_sample_backward")
+            if plan is not None and M > 0:
+                rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
+                                            _ptr(samples), _ptr(gouts[0]), _ptr(gouts[1]), _ptr(gouts[2]),
+                                            _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics), _ptr(g_values),
+                                            _stream(means.device))
+                _lib.check(rc, "pigs_plan_backward")
+            else:
+                rc = lib.pigs_sample_backward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
+                                              _ptr(values), _ptr(samples), _ptr(gouts[0]), _ptr(gouts[1]),
+                                              _ptr(gouts[2]), _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics),
+                                              _ptr(g_values), _stream(means.device))
+                _lib.check(rc, "pigs_sample_backward")
     return g_means, g_values, g_conics
 
 
@@ -90,13 +129,14 @@ class _SampleFunction(torch.autograd.Function):
     fused launch over the outputs that received a gradient."""
 
     @staticmethod
-    def forward(ctx, means, values, conics, samples, mask, debug):
-        outs = forward_raw(means, values, conics, samples, mask)
+    def forward(ctx, means, values, conics, samples, mask, debug, plan):
+        outs = forward_raw(means, values, conics, samples, mask, plan)
         if debug:
             torch.cuda.synchronize(means.device)
         ctx.save_for_backward(means, values, conics, samples)
         ctx.mask = mask
         ctx.debug = debug
+        ctx.plan = plan
         ctx.set_materialize_grads(False)
         return tuple(outs[k] for k in _mask_orders(mask))
 
@@ -111,11 +151,11 @@ class _SampleFunction(torch.autograd.Function):
                 gouts[k] = g.contiguous()
                 mask |= 1 << k
         if mask == 0:
-            return None, None, None, None, None, None
-        g_means, g_values, g_conics = backward_raw(means, values, conics, samples, gouts, mask)
+            return None, None, None, None, None, None, None
+        g_means, g_values, g_conics = backward_raw(means, values, conics, samples, gouts, mask, ctx.plan)
         if ctx.debug:
             torch.cuda.synchronize(means.device)
-        return g_means, g_values, g_conics, None, None, None
+        return g_means, g_values, g_conics, None, None, None, None
 
 
 class GaussianSampler:
@@ -125,6 +165,11 @@ class GaussianSampler:
     False in model_pn.py:423; meaning not visible in the reference).  Here it is a debug switch:
     when set, every launch is followed by a device synchronise so that errors surface at the call.
 
+    ``backend`` (extension, keyword only): ``"dense"`` evaluates every (point, Gaussian) pair --
+    the reference's dense semantics exactly; ``"binned"`` builds the culling plan in ``preprocess``
+    and drops pairs with q > ``q_max`` (relative truncation below exp(-q_max/2)); ``"auto"`` picks
+    binned for float32, d = 2, c <= 3 once N*M >= 2**24 pairs, where the plan pays for itself.
+
     ``fuse`` (extension, keyword only) controls how many derivative orders one launch computes:
     ``"auto"`` -- the first ``sample_*`` call after a ``preprocess`` computes orders 0..2 in one
     launch when the problem is small enough to be launch-bound (M <= 65536), otherwise only the
@@ -133,13 +178,21 @@ class GaussianSampler:
     """
 
     FUSE_AUTO_MAX_POINTS = 1 << 16
+    BINNED_AUTO_MIN_PAIRS = 1 << 24
 
-    def __init__(self, flag=False, *, fuse="auto"):
+    def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
+        if backend not in ("auto", "dense", "binned"):
+            raise ValueError("backend must be 'auto', 'dense' or 'binned'")
+        if not q_max > 0:
+            raise ValueError("q_max must be positive")
         self.debug = bool(flag)
         self.fuse = fuse
+        self.backend = backend
+        self.q_max = float(q_max)
         self._inputs = None
+        self._plan = None
         self._cache = {}
         _lib.load()  # fail at construction, not at first use, if the HIP library is missing
 
@@ -191,6 +244,17 @@ class GaussianSampler:
         self._inputs = (means.contiguous(), values.contiguous(), conics.contiguous(),
                         samples.detach().contiguous())
         self._cache = {}
+        self._plan = None
+        mc, vc, cc, sc = self._inputs
+        use_plan = self.backend == "binned" or (
+            self.backend == "auto" and N * sc.shape[0] >= self.BINNED_AUTO_MIN_PAIRS)
+        if use_plan and Plan.supported(mc, vc, sc):
+            with torch.no_grad():
+                self._plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, self.q_max)
+            if self.debug:
+                torch.cuda.synchronize(means.device)
+        elif self.backend == "binned" and N > 0 and sc.shape[0] > 0:
+            raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 3")
 
     # ------------------------------------------------------------------ sampling
     def _require_inputs(self):
@@ -200,7 +264,7 @@ class GaussianSampler:
 
     def _compute(self, mask):
         means, values, conics, samples = self._require_inputs()
-        outs = _SampleFunction.apply(means, values, conics, samples, mask, self.debug)
+        outs = _SampleFunction.apply(means, values, conics, samples, mask, self.debug, self._plan)
         for k, o in zip(_mask_orders(mask), outs):
             self._cache[k] = o
 

@@ -1,0 +1,217 @@
+"""GPU parity of the binned (culled) path: preprocess plan + forward + backward against the dense
+CPU oracle.  The cut-off (q_max = 36) drops terms below e^-18 of a term's scale, so the bar stays
+1e-5 relative (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def dev32(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def Sampler(hip_lib):
+    assert torch.cuda.is_available()
+    from diff_gaussian_sampling import GaussianSampler
+    return GaussianSampler
+
+
+def random_gaussians(rng, N, c, log_sigma_mean=-3.5, log_sigma_std=0.6, lo=-1.0, hi=1.0):
+    means = rng.uniform(lo, hi, (N, 2))
+    s0 = np.exp(2 * rng.normal(log_sigma_mean, log_sigma_std, (N, 2)))      # variances
+    tau = np.tanh(rng.normal(0, 0.7, N)) * np.sqrt(s0[:, 0] * s0[:, 1])
+    det = s0[:, 0] * s0[:, 1] - tau ** 2
+    con = np.stack((s0[:, 1] / det, -tau / det, s0[:, 0] / det), -1)
+    values = rng.uniform(-1, 1, (N, c))
+    return means, con, values
+
+
+def check_case(Sampler, means, con, values, samples, orders=(0, 1, 2, 3), bwd=True, tol=TOL):
+    t = [dev32(a) for a in (means, values, con, samples)]
+    for x in t[:3]:
+        x.requires_grad_(True)
+    s = Sampler(True, backend="binned", fuse="none")
+    s.preprocess(t[0], t[1], None, t[2], t[3])
+    assert s._plan is not None
+    outs = s.sample(orders)
+    args = [x.detach().cpu().double().numpy() for x in (t[0], t[2], t[1], t[3])]
+    exp = c_oracle.forward(*args, orders=orders)
+    rng = np.random.default_rng(1)
+    loss, rs = 0, {}
+    for o, out in zip(orders, outs):
+        assert out.shape == exp[o].shape
+        assert rel(out, exp[o]) < tol, ("order", o, rel(out, exp[o]))
+        rs[o] = dev32(rng.uniform(-1, 1, exp[o].shape))
+        loss = loss + (out * rs[o]).sum()
+    if not bwd:
+        return
+    loss.backward()
+    em, ec, ev = c_oracle.backward(*args, {o: r.cpu().double().numpy() for o, r in rs.items()})
+    assert rel(t[0].grad, em) < tol, ("means", rel(t[0].grad, em))
+    assert rel(t[1].grad, ev) < tol, ("values", rel(t[1].grad, ev))
+    assert rel(t[2].grad, ec) < tol, ("conics", rel(t[2].grad, ec))
+
+
+@pytest.mark.parametrize("N,M,c", [(1, 1, 1), (7, 3, 2), (500, 2000, 1), (3000, 5000, 2), (2048, 4096, 3)])
+def test_random_points_and_gaussians(Sampler, N, M, c):
+    rng = np.random.default_rng(N + M)
+    means, con, values = random_gaussians(rng, N, c)
+    samples = rng.uniform(-1.2, 1.2, (M, 2))
+    check_case(Sampler, means, con, values, samples)
+
+
+def test_mixed_scales_fill_every_level(Sampler):
+    """Gaussians from far below the finest cell to larger than the whole domain."""
+    rng = np.random.default_rng(3)
+    N = 1500
+    means, con, values = random_gaussians(rng, N, 1, log_sigma_mean=-3.0, log_sigma_std=1.8)
+    samples = rng.uniform(-1.5, 1.5, (3000, 2))
+    check_case(Sampler, means, con, values, samples)
+
+
+def test_regular_grid_samples(Sampler):
+    """test_gaussian_sampling.py:42-46 shape: meshgrid(indexing='xy') grid, x fastest."""
+    from pigs_amd import synthetic
+    gs = synthetic.lattice_gaussians(32, 32, kappa=0.7, seed=2)
+    pts = synthetic.grid_samples(96)
+    check_case(Sampler, gs["means"].numpy(), gs["conics"].numpy(), gs["values"].numpy(), pts.numpy())
+
+
+def test_clustered_points_multiple_passes(Sampler):
+    """Hundreds of points in one sample cell (several 64-lane passes) + a few outliers."""
+    rng = np.random.default_rng(4)
+    means, con, values = random_gaussians(rng, 400, 1)
+    cluster = rng.normal(0.2, 1e-3, (700, 2))
+    samples = np.concatenate((cluster, rng.uniform(-1, 1, (50, 2)), np.array([[5.0, -7.0]])))
+    check_case(Sampler, means, con, values, samples)
+
+
+def test_degenerate_geometry(Sampler):
+    rng = np.random.default_rng(5)
+    means, con, values = random_gaussians(rng, 300, 1)
+    # all points identical
+    check_case(Sampler, means, con, values, np.tile([[0.1, 0.2]], (130, 1)))
+    # all points on a vertical line
+    line = np.stack((np.full(500, 0.3), np.linspace(-1, 1, 500)), -1)
+    check_case(Sampler, means, con, values, line)
+    # all Gaussians at one centre
+    means0 = np.tile([[0.0, 0.0]], (300, 1))
+    check_case(Sampler, means0, con, values, rng.uniform(-0.5, 0.5, (400, 2)))
+    # samples far outside the Gaussians' domain (everything culled -> exact zeros expected)
+    far = rng.uniform(50, 51, (100, 2))
+    t = [dev32(a) for a in (means, values, con, far)]
+    s = Sampler(True, backend="binned")
+    s.preprocess(t[0], t[1], None, t[2], t[3])
+    assert not s.sample_gaussians().any() and not s.sample_gaussians_laplacian().any()
+
+
+def test_truncation_at_cutoff_border(Sampler):
+    """Points placed exactly around the q = q_max contour of isolated Gaussians: the dropped
+    term is ~e^-18 of the peak, far below the bar, for every order."""
+    rng = np.random.default_rng(6)
+    N = 64
+    means = np.stack(np.meshgrid(np.linspace(-1, 1, 8), np.linspace(-1, 1, 8)), -1).reshape(N, 2)
+    sig = 0.01
+    con = np.tile([1 / sig ** 2, 0.0, 1 / sig ** 2], (N, 1))
+    values = np.ones((N, 1))
+    ang = rng.uniform(0, 2 * np.pi, (N, 40))
+    rad = sig * np.sqrt(36.0) * rng.uniform(0.9, 1.1, (N, 40))
+    ring = means[:, None, :] + np.stack((np.cos(ang), np.sin(ang)), -1) * rad[..., None]
+    samples = np.concatenate((ring.reshape(-1, 2), means))    # the centres set the output scale
+    check_case(Sampler, means, con, values, samples)
+
+
+def test_single_orders_and_fused_agree(Sampler):
+    rng = np.random.default_rng(7)
+    means, con, values = random_gaussians(rng, 800, 2)
+    samples = rng.uniform(-1, 1, (1500, 2))
+    t = [dev32(a) for a in (means, values, con, samples)]
+    a = Sampler(False, backend="binned", fuse="none")
+    a.preprocess(t[0], t[1], None, t[2], t[3])
+    singles = (a.sample_gaussians(), a.sample_gaussians_derivative(), a.sample_gaussians_laplacian(),
+               a.sample_gaussians_third_derivative())
+    b = Sampler(False, backend="binned")
+    b.preprocess(t[0], t[1], None, t[2], t[3])
+    fused = b.sample((0, 1, 2, 3))
+    for x, y in zip(singles, fused):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-6 * float(x.abs().max()))
+
+
+def test_binned_equals_dense_hip(Sampler):
+    rng = np.random.default_rng(8)
+    means, con, values = random_gaussians(rng, 1200, 1)
+    samples = rng.uniform(-1, 1, (2500, 2))
+    t = [dev32(a) for a in (means, values, con, samples)]
+    outs = {}
+    for backend in ("dense", "binned"):
+        s = Sampler(False, backend=backend)
+        s.preprocess(t[0], t[1], None, t[2], t[3])
+        outs[backend] = s.sample((0, 1, 2))
+    for x, y in zip(outs["dense"], outs["binned"]):
+        assert float((x - y).abs().max() / x.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("kappa", [0.5, 1.3])
+def test_config2_binned_8k_x_256sq(Sampler, kappa):
+    from pigs_amd import synthetic
+    gs, pts = synthetic.CONFIGS["c2"](kappa)
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    for k in ("means", "values", "conics"):
+        t[k].requires_grad_(True)
+    pts = pts.float().cuda()
+    s = Sampler(False, fuse="all")
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+    assert s._plan is not None          # auto picks the binned path at this size
+    u, ux, uxx = s.sample((0, 1, 2))
+    idx = torch.arange(0, pts.shape[0], 16, device="cuda")
+    args = [t[k].detach().cpu().double().numpy() for k in ("means", "conics", "values")]
+    exp = c_oracle.forward(*args, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
+    for o, out in enumerate((u, ux, uxx)):
+        assert rel(out[idx], exp[o]) < TOL, o
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rs = [torch.rand(e.shape, generator=g, dtype=torch.float64) * 2 - 1 for e in (exp[0], exp[1], exp[2])]
+    loss = sum((out[idx] * r.float().cuda()).sum() for out, r in zip((u, ux, uxx), rs))
+    loss.backward()
+    em, ec, ev = c_oracle.backward(*args, pts[idx].cpu().double().numpy(),
+                                   {o: r.float().double().numpy() for o, r in enumerate(rs)})
+    assert rel(t["means"].grad, em) < TOL
+    assert rel(t["values"].grad, ev) < TOL
+    assert rel(t["conics"].grad, ec) < TOL
+
+
+@pytest.mark.parametrize("kappa", [0.5, 1.3])
+def test_config3_65k_x_1024sq_forward(Sampler, kappa):
+    """BASELINE.json configs[2] at full size: oracle on 2048 sampled points; plus the
+    size-independent property that every output is invariant under a permutation of the
+    sample points (the sort inside preprocess must not leak into the results)."""
+    from pigs_amd import synthetic
+    gs, pts = synthetic.CONFIGS["c3"](kappa)
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    pts = pts.float().cuda()
+    s = Sampler(False, fuse="all")
+    with torch.no_grad():
+        s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+        u, ux, uxx = s.sample((0, 1, 2))
+    idx = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))[:2048].cuda()
+    args = [t[k].cpu().double().numpy() for k in ("means", "conics", "values")]
+    exp = c_oracle.forward(*args, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
+    for o, out in enumerate((u, ux, uxx)):
+        assert rel(out[idx], exp[o]) < TOL, o
+        assert torch.isfinite(out).all()
+    # permutation invariance on a 64k-point subset
+    sub = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(4))[:65536].cuda()
+    with torch.no_grad():
+        s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts[sub].contiguous())
+        v = s.sample_gaussians_laplacian()
+    assert float((v - uxx[sub]).abs().max() / uxx.abs().max()) < 2e-6
