@@ -56,7 +56,7 @@ def host_cores():
     return max(1, min(cores, 16))
 
 
-def cpu_baseline(gs, pts, budget_pairs=1.3e8):
+def cpu_baseline(gs, pts, budget_pairs=6e8):
     """The reference's dense PyTorch algorithm (oracle/dense_torch.py) on the host cores, on a
     bounded slice of the same workload; linear in M, so points/s extrapolates."""
     from oracle import dense_torch

@@ -55,12 +55,15 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // preprocess kernels
 // ------------------------------------------------------------------------------------------
 struct BuildArgs {
-    PlanHeader* header;
-    uint32_t* starts;     // counts, then (in place) their exclusive scan
-    uint32_t* cursor;
-    uint32_t* blocksum;
-    uint32_t* gkey;
-    uint32_t* skey;
+    PlanScratch* scratch;
+    PlanParams* params;
+    BoxPartial* boxes;    // [PLAN_BBOX_BLOCKS]
+    uint32_t* counts;     // Gaussian cell counters at [0, gcells), sample cell counters at
+                          // [sbase, sbase + scells_cap); followed by the scan aggregates
+    unsigned long long* agg;   // [scan_blocks] {1 << 32 | workgroup total}, zero before the scan
+    uint32_t* starts;     // [ncounts + 1] exclusive scan of counts
+    uint2* gkey;          // per Gaussian {cell key, rank inside the cell}
+    uint2* skey;          // per point    {cell id,  rank inside the cell}
     float4* rec;
     uint32_t* g2o;
     uint32_t* perm;
@@ -70,142 +73,229 @@ struct BuildArgs {
     const float* samples;
     uint32_t N, M;
     int c, G0, L;
-    uint32_t gcells, scells_cap, ncounts;
+    uint32_t sbase, scells_cap, ncounts, zero_words;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     float q_max;
 };
 
-__global__ __launch_bounds__(256) void plan_init_kernel(BuildArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i <= a.ncounts) a.starts[i] = 0;
-    if (i == 0) {
-        a.header->gbox[0] = a.header->gbox[1] = a.header->sbox[0] = a.header->sbox[1] = 0x7fffffff;
-        a.header->gbox[2] = a.header->gbox[3] = a.header->sbox[2] = a.header->sbox[3] = (int32_t)0x80000000;
-        a.header->level_mask = 0;
-    }
-}
-
-__device__ __forceinline__ void bbox_accumulate(const float2* __restrict__ pts, uint32_t n, int32_t* box) {
+// Launch 1 (PLAN_BBOX_BLOCKS workgroups): zero the cell counters; per-workgroup bounding boxes
+// of the Gaussian centres and of the sample points, 8 float4 loads (16 points) in flight per
+// thread, written as plain partials.
+__device__ __forceinline__ void bbox_partial(const float4* __restrict__ pts2, const float2* __restrict__ pts,
+                                             uint32_t n, float* out, float (*sh)[4]) {
     const float INF = __builtin_huge_valf();
     float x0 = INF, y0 = INF, x1 = -INF, y1 = -INF;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float2 p = pts[i];
-        if (fabsf(p.x) < INF) { x0 = fminf(x0, p.x); x1 = fmaxf(x1, p.x); }
-        if (fabsf(p.y) < INF) { y0 = fminf(y0, p.y); y1 = fmaxf(y1, p.y); }
+    auto take = [&](float x, float y) {
+        if (fabsf(x) < INF) { x0 = fminf(x0, x); x1 = fmaxf(x1, x); }
+        if (fabsf(y) < INF) { y0 = fminf(y0, y); y1 = fmaxf(y1, y); }
+    };
+    const uint32_t npair = n / 2;                 // float4 = two points
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npair; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t j = i + k * stride;
+            v[k] = pts2[j < npair ? j : i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
     }
+    if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) take(pts[n - 1].x, pts[n - 1].y);
     x0 = wave_min_bcast(x0); y0 = wave_min_bcast(y0);
     x1 = wave_max_bcast(x1); y1 = wave_max_bcast(y1);
-    if ((threadIdx.x & 63) == 0) {
-        if (x0 <= x1) { atomicMin(&box[0], float_to_ordered(x0)); atomicMax(&box[2], float_to_ordered(x1)); }
-        if (y0 <= y1) { atomicMin(&box[1], float_to_ordered(y0)); atomicMax(&box[3], float_to_ordered(y1)); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            x0 = fminf(x0, sh[w][0]); y0 = fminf(y0, sh[w][1]);
+            x1 = fmaxf(x1, sh[w][2]); y1 = fmaxf(y1, sh[w][3]);
+        }
+        out[0] = x0; out[1] = y0; out[2] = x1; out[3] = y1;
     }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void plan_bbox_kernel(BuildArgs a) {
-    bbox_accumulate((const float2*)a.means, a.N, a.header->gbox);
-    bbox_accumulate((const float2*)a.samples, a.M, a.header->sbox);
+    __shared__ float sh[4][4];
+    uint4* c4 = (uint4*)a.counts;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.zero_words / 4; i += gridDim.x * 256)
+        c4[i] = make_uint4(0, 0, 0, 0);
+    bbox_partial((const float4*)a.means, (const float2*)a.means, a.N, a.boxes[blockIdx.x].g, sh);
+    bbox_partial((const float4*)a.samples, (const float2*)a.samples, a.M, a.boxes[blockIdx.x].s, sh);
+}
+
+// every workgroup of the count kernel reduces the PLAN_BBOX_BLOCKS partials (4 KB, L2 resident)
+__device__ __forceinline__ void reduce_boxes(const BoxPartial* boxes, float* gbox, float* sbox, float (*sh)[8]) {
+    const float INF = __builtin_huge_valf();
+    float v[8] = {INF, INF, -INF, -INF, INF, INF, -INF, -INF};
+    if (threadIdx.x < PLAN_BBOX_BLOCKS) {
+        const float4* p = (const float4*)&boxes[threadIdx.x];
+        const float4 g = p[0], s = p[1];
+        v[0] = g.x; v[1] = g.y; v[2] = g.z; v[3] = g.w; v[4] = s.x; v[5] = s.y; v[6] = s.z; v[7] = s.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (k & 2) ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh[wave][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float r = sh[0][k];
+        for (int w = 1; w < (PLAN_BBOX_BLOCKS + 63) / 64; ++w) r = (k & 2) ? fmaxf(r, sh[w][k]) : fminf(r, sh[w][k]);
+        (k < 4 ? gbox : sbox)[k & 3] = r;
+    }
+}
+
+// Launch 2: cell key of every Gaussian / point and its rank inside the cell, with ONE returning
+// atomic per run of equal keys in a wave (points of a regular grid arrive in runs that share a
+// cell): the run leader adds the run length to the cell counter, the others take consecutive
+// ranks behind it.  run_* split the step so that several independent atomics are in flight.
+struct Run { int start; uint32_t len; bool leader; };
+__device__ __forceinline__ Run run_of(uint32_t k, int lane) {
+    const uint32_t prev = __shfl_up(k, 1);
+    Run r;
+    r.leader = lane == 0 || k != prev;
+    const uint64_t lm = __ballot(r.leader);
+    const uint64_t upto = (2ull << lane) - 1ull;          // bits 0..lane (lane 63: all ones)
+    r.start = 63 - __builtin_clzll(lm & upto);
+    const uint64_t above = lm & ~upto;
+    r.len = (uint32_t)((above ? __builtin_ctzll(above) : 64) - lane);   // meaningful for leaders
+    return r;
 }
 
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < a.N) {
-        const GaussGrid g = gauss_grid(a.header, a.G0);
-        const float mx = a.means[2 * i], my = a.means[2 * i + 1];
-        const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
-        // half extents of the q <= q_max ellipse: sqrt(q_max * Sigma_xx), Sigma = C^-1
-        const float det = ca * cc - cb * cb;
-        const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
+    __shared__ float shb[4][8];
+    const int lane = threadIdx.x & 63;
+    float gbox[4], sbox[4];
+    reduce_boxes(a.boxes, gbox, sbox, shb);
+    const GaussGrid g = gauss_grid(gbox, a.G0);
+    const SampleGrid sg = sample_grid(sbox, a.M, a.scells_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.params->gg = g;
+        a.params->sg = sg;
+    }
+    if (blockIdx.x * 256 < a.N) {       // block-uniform: whole waves enter
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        const bool valid = i < a.N;
+        uint32_t key = 0xffffffffu;
         int l = 0;
-        float s = g.s0;
-        while (l < a.L - 1 && !(R <= s)) { ++l; s *= 2.f; }
-        const int G = a.G0 >> l;
-        const float inv_s = 1.f / s;
-        const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
-        const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
-        const uint32_t key = a.level_off[l] + (uint32_t)(cy * G + cx);
-        a.gkey[i] = key;
-        atomicAdd(&a.starts[key], 1u);
-        if (!(*(volatile uint32_t*)&a.header->level_mask >> l & 1u)) atomicOr(&a.header->level_mask, 1u << l);
-    }
-    if (i < a.M) {
-        const SampleGrid sg = sample_grid(a.header, a.M, a.scells_cap);
-        const float x = a.samples[2 * i], y = a.samples[2 * i + 1];
-        const int cx = (int)clampf((x - sg.ox) * sg.inv_w, 0.f, (float)(sg.nx - 1));
-        const int cy = (int)clampf((y - sg.oy) * sg.inv_w, 0.f, (float)(sg.ny - 1));
-        const uint32_t id = sample_cell_id(cx, cy, sg.nx);
-        a.skey[i] = id;
-        atomicAdd(&a.starts[a.gcells + id], 1u);
-    }
-}
-
-// exclusive scan of starts[0 .. ncounts) in place, 4096 elements per block, two launches
-constexpr int SCAN_PER_THREAD = 16;
-constexpr int SCAN_PER_BLOCK = 256 * SCAN_PER_THREAD;
-
-__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* sh) {
-    // returns the block total in every thread
+        if (valid) {
+            const float mx = a.means[2 * i], my = a.means[2 * i + 1];
+            const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
+            // half extents of the q <= q_max ellipse: sqrt(q_max * Sigma_xx), Sigma = C^-1
+            const float det = ca * cc - cb * cb;
+            const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
+            float s = g.s0;
+            while (l < a.L - 1 && !(R <= s)) { ++l; s *= 2.f; }
+            const int G = a.G0 >> l;
+            const float inv_s = 1.f / s;
+            const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
+            const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
+            key = a.level_off[l] + (uint32_t)(cy * G + cx);
+        }
+        const Run r = run_of(key, lane);
+        uint32_t base = 0;
+        if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
+        base = __shfl(base, r.start);
+        if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
+        // one atomicOr per wave, and only for levels not yet recorded
+        uint32_t lv = valid ? 1u << l : 0u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const uint32_t t = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-    return t;
+        for (int o = 32; o > 0; o >>= 1) lv |= __shfl_xor(lv, o);
+        if (lane == 0 && (lv & ~*(volatile uint32_t*)&a.scratch->level_mask)) atomicOr(&a.scratch->level_mask, lv);
+    }
+    if (blockIdx.x * 1024 < a.M) {
+        // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
+        const uint32_t i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + lane;
+        uint32_t id[4], base[4];
+        Run r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            id[k] = 0xffffffffu;
+            if (i < a.M) {
+                const float2 p = ((const float2*)a.samples)[i];
+                const int cx = (int)clampf((p.x - sg.ox) * sg.inv_w, 0.f, (float)(sg.nx - 1));
+                const int cy = (int)clampf((p.y - sg.oy) * sg.inv_w, 0.f, (float)(sg.ny - 1));
+                id[k] = sample_cell_id(cx, cy, sg.nx);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = run_of(id[k], lane);
+            base[k] = 0;
+            if (r[k].leader && id[k] != 0xffffffffu)
+                base[k] = atomicAdd(&a.counts[a.sbase + id[k]], r[k].len);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            const uint32_t b = __shfl(base[k], r[k].start);
+            if (i < a.M) a.skey[i] = make_uint2(id[k], b + (uint32_t)(lane - r[k].start));
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void plan_scan_blocksum_kernel(BuildArgs a) {
+// Launch 3: exclusive scan counts -> starts in ONE launch.  A workgroup scans PLAN_SCAN_BLOCK
+// counters (one coalesced uint4 per thread), publishes its total as one 8-byte {flag, total}
+// granule (single agent-scope store: data and flag travel together, no fence needed) and sums
+// the granules of the workgroups before it; nobody waits on a later workgroup, so dispatch
+// order cannot deadlock it.
+__global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     __shared__ uint32_t sh[4];
-    const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) s += (base + k < a.ncounts) ? a.starts[base + k] : 0u;
-    const uint32_t t = block_sum_256(s, sh);
-    if (threadIdx.x == 0) a.blocksum[blockIdx.x] = t;
-}
-
-__global__ __launch_bounds__(256) void plan_scan_apply_kernel(BuildArgs a) {
-    __shared__ uint32_t sh[4];
-    __shared__ uint32_t wave_tot[4];
-    // offset of this block = sum of the preceding block sums
-    uint32_t pre = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) pre += a.blocksum[b];
-    const uint32_t offset = block_sum_256(pre, sh);
-    const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD];
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        v[k] = (base + k < a.ncounts) ? a.starts[base + k] : 0u;
-        s += v[k];
-    }
-    // exclusive scan of the per-thread sums across the block
+    __shared__ uint32_t sh2[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;          // uint4 index
+    const uint4 v = ((const uint4*)a.counts)[q];
+    const uint32_t s = v.x + v.y + v.z + v.w;
     uint32_t inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t t = __shfl_up(inc, o);
         if (lane >= o) inc += t;
     }
-    if (lane == 63) wave_tot[wave] = inc;
+    if (lane == 63) sh[wave] = inc;
     __syncthreads();
-    uint32_t run = offset + inc - s;
-    for (int w = 0; w < wave; ++w) run += wave_tot[w];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        if (base + k < a.ncounts) {
-            a.starts[base + k] = run;
-            a.cursor[base + k] = run;
-        }
-        run += v[k];
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&a.agg[blockIdx.x], (1ull << 32) | (sh[0] + sh[1] + sh[2] + sh[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t pre = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) {
+        unsigned long long x;
+        do {
+            x = __hip_atomic_load(&a.agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(x >> 32)) __builtin_amdgcn_s_sleep(1);
+        } while (!(x >> 32));
+        pre += (uint32_t)x;
     }
-    // total = N + M: every Gaussian and every point was counted exactly once
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.starts[a.ncounts] = a.N + a.M;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    if (lane == 0) sh2[wave] = pre;
+    __syncthreads();
+    uint32_t run = inc - s + sh2[0] + sh2[1] + sh2[2] + sh2[3];
+    for (int w = 0; w < wave; ++w) run += sh[w];
+    uint4 o4;
+    o4.x = run; o4.y = run + v.x; o4.z = o4.y + v.y; o4.w = o4.z + v.z;
+    ((uint4*)a.starts)[q] = o4;      // counters beyond ncounts are zero: starts[ncounts] = total
 }
 
+// Launch 4: scatter into sorted order (no atomics: position = cell start + rank), publish the
+// level mask and hand the scratch back zeroed.
 __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        a.params->level_mask = a.scratch->level_mask;
+        uint32_t* z = (uint32_t*)a.scratch;
+        for (uint32_t k = 0; k < sizeof(PlanScratch) / 4; ++k) z[k] = 0;
+    }
     if (i < a.N) {
-        const uint32_t pos = atomicAdd(&a.cursor[a.gkey[i]], 1u);
+        const uint2 kr = a.gkey[i];
+        const uint32_t pos = a.starts[kr.x] + kr.y;
         float v[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
         a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
@@ -213,8 +303,8 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         a.g2o[pos] = i;
     }
     if (i < a.M) {
-        const uint32_t pos = atomicAdd(&a.cursor[a.gcells + a.skey[i]], 1u) - a.N;
-        a.perm[pos] = i;
+        const uint2 kr = a.skey[i];
+        a.perm[a.starts[a.sbase + kr.x] - a.N + kr.y] = i;
     }
 }
 
@@ -300,11 +390,11 @@ __global__ __launch_bounds__(256) void binned_forward_kernel(PlanView pv, const 
     using L = FwdLayout<2, C, MASK>;
     const int lane = threadIdx.x & 63;
     const uint32_t cell = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t sbeg = pv.starts[pv.gcells + cell] - pv.N;
-    const uint32_t send = pv.starts[pv.gcells + cell + 1] - pv.N;
+    const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
+    const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
     if (sbeg >= send) return;
-    const GaussGrid gg = gauss_grid(pv.header, pv.G0);
-    const uint32_t level_mask = pv.header->level_mask;
+    const GaussGrid gg = pv.params->gg;
+    const uint32_t level_mask = pv.params->level_mask;
     const float INF = __builtin_huge_valf();
 
     for (uint32_t base = sbeg; base < send; base += 64) {
@@ -349,11 +439,11 @@ __global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const
     using BL = BwdLayout<2, C>;
     const int lane = threadIdx.x & 63;
     const uint32_t cell = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t sbeg = pv.starts[pv.gcells + cell] - pv.N;
-    const uint32_t send = pv.starts[pv.gcells + cell + 1] - pv.N;
+    const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
+    const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
     if (sbeg >= send) return;
-    const GaussGrid gg = gauss_grid(pv.header, pv.G0);
-    const uint32_t level_mask = pv.header->level_mask;
+    const GaussGrid gg = pv.params->gg;
+    const uint32_t level_mask = pv.params->level_mask;
     const float INF = __builtin_huge_valf();
 
     for (uint32_t base = sbeg; base < send; base += 64) {
@@ -431,14 +521,14 @@ __global__ __launch_bounds__(256) void plan_unpermute_kernel(PlanView pv, float*
 static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     char* b = (char*)ws;
     PlanView v{};
-    v.header = (const PlanHeader*)(b + p.off_header);
+    v.params = (const PlanParams*)(b + p.off_params);
     v.starts = (const uint32_t*)(b + p.off_starts);
     v.rec = (const float4*)(b + p.off_rec);
     v.g2o = (const uint32_t*)(b + p.off_g2o);
     v.perm = (const uint32_t*)(b + p.off_perm);
     v.N = (uint32_t)p.N; v.M = (uint32_t)p.M;
     v.G0 = p.G0; v.L = p.L;
-    v.gcells = p.gcells; v.scells_cap = p.scells_cap;
+    v.sbase = p.sbase; v.scells_cap = p.scells_cap;
     for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) v.level_off[l] = p.level_off[l];
     v.q_max = q_max;
     v.gacc = (float*)(b + p.off_gacc);
@@ -450,45 +540,47 @@ static bool plan_supported(int64_t N, int64_t M, int c) {
            N + M < (1LL << 32) - 1;
 }
 
+size_t plan_scratch_bytes() { return PLAN_SCRATCH_BYTES; }
+
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
     if (!plan_supported(N, M, c)) return 0;
     return make_plan_layout(N, M, c).total_bytes;
 }
 
-int plan_build(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, const void* means,
-               const void* conics, const void* values, const void* samples, hipStream_t stream) {
+int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, int c, float q_max,
+               const void* means, const void* conics, const void* values, const void* samples,
+               hipStream_t stream) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
-    if (!(q_max > 0.f)) return PIGS_ERR_INVALID;
+    if (!(q_max > 0.f) || !scratch) return PIGS_ERR_INVALID;
     const PlanLayout p = make_plan_layout(N, M, c);
     if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
     char* b = (char*)ws;
     BuildArgs a{};
-    a.header = (PlanHeader*)(b + p.off_header);
+    a.scratch = (PlanScratch*)scratch;
+    a.params = (PlanParams*)(b + p.off_params);
+    a.boxes = (BoxPartial*)(b + p.off_boxes);
+    a.counts = (uint32_t*)(b + p.off_counts);
+    a.agg = (unsigned long long*)(b + p.off_agg);
     a.starts = (uint32_t*)(b + p.off_starts);
-    a.cursor = (uint32_t*)(b + p.off_cursor);
-    a.blocksum = (uint32_t*)(b + p.off_blocksum);
-    a.gkey = (uint32_t*)(b + p.off_gkey);
-    a.skey = (uint32_t*)(b + p.off_skey);
+    a.gkey = (uint2*)(b + p.off_gkey);
+    a.skey = (uint2*)(b + p.off_skey);
     a.rec = (float4*)(b + p.off_rec);
     a.g2o = (uint32_t*)(b + p.off_g2o);
     a.perm = (uint32_t*)(b + p.off_perm);
     a.means = (const float*)means; a.conics = (const float*)conics;
     a.values = (const float*)values; a.samples = (const float*)samples;
     a.N = (uint32_t)N; a.M = (uint32_t)M; a.c = c; a.G0 = p.G0; a.L = p.L;
-    a.gcells = p.gcells; a.scells_cap = p.scells_cap; a.ncounts = p.ncounts;
+    a.sbase = p.sbase; a.scells_cap = p.scells_cap; a.ncounts = p.ncounts;
+    a.zero_words = (uint32_t)((p.off_starts - p.off_counts) / 4);     // counters + aggregates
     for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.level_off[l] = p.level_off[l];
     a.q_max = q_max;
 
     clear_hip_error();
     const uint32_t nmax = (uint32_t)(N > M ? N : M);
-    const uint32_t scan_blocks = (p.ncounts + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
-    hipLaunchKernelGGL(plan_init_kernel, dim3(p.ncounts / 256 + 1), dim3(256), 0, stream, a);
-    uint32_t bbox_blocks = (nmax + 255) / 256;
-    if (bbox_blocks > 1024) bbox_blocks = 1024;
-    hipLaunchKernelGGL(plan_bbox_kernel, dim3(bbox_blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(plan_count_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(plan_scan_blocksum_kernel, dim3(scan_blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(plan_scan_apply_kernel, dim3(scan_blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
+    const uint32_t gb = (uint32_t)((N + 255) / 256), sb = (uint32_t)((M + 1023) / 1024);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(gb > sb ? gb : sb), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(p.scan_blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(plan_scatter_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, a);
     return launch_status();
 }

@@ -28,16 +28,43 @@
 namespace pigs {
 
 constexpr int PLAN_MAX_LEVELS = 12;
+constexpr uint32_t PLAN_SCAN_BLOCK = 256 * 4;     // counters scanned per workgroup (one uint4 per thread)
+
 constexpr int PLAN_POINTS_PER_CELL = 63;   // target occupancy of a 64-lane sample cell: a regular grid then
                                             // yields cells of 49..64 points (never a second pass); for Poisson
                                             // counts the short second passes cost about what emptier cells would
 
 // Device-resident header (first bytes of the workspace), written by the preprocess kernels.
-struct PlanHeader {
-    int32_t gbox[4];     // Gaussian centres: min x, min y, max x, max y (ordered-int encoded floats)
-    int32_t sbox[4];     // sample points, same encoding
+// Caller-provided persistent scratch of the build (PLAN_SCRATCH_BYTES, zero before the first
+// build; every build leaves it zero again, so builds sharing one scratch must be stream ordered).
+struct PlanScratch {
     uint32_t level_mask; // bit l set = level l holds at least one Gaussian
-    uint32_t pad[7];
+    uint32_t pad1[63];
+};
+constexpr size_t PLAN_SCRATCH_BYTES = sizeof(PlanScratch);
+
+// Per-workgroup partial bounding boxes written by the first build kernel (plain stores; same-
+// address atomics serialise at ~10 ns each, so no atomics here) and reduced again by every
+// workgroup of the second.
+constexpr int PLAN_BBOX_BLOCKS = 128;
+struct BoxPartial {
+    float g[4];   // Gaussian centres: min x, min y, max x, max y (+-inf when empty)
+    float s[4];   // sample points
+};
+
+struct GaussGrid {
+    float ox, oy, inv_s0, s0;
+};
+struct SampleGrid {
+    float ox, oy, inv_w;
+    int nx, ny;   // even
+};
+// Written once by the build (first bytes of the workspace), read by the sampling kernels.
+struct PlanParams {
+    GaussGrid gg;
+    SampleGrid sg;
+    uint32_t level_mask;
+    uint32_t pad[6];
 };
 
 // Host+device view of the workspace (plain offsets; computed identically by every entry point
@@ -48,10 +75,12 @@ struct PlanLayout {
     int G0, L;                 // finest Gaussian grid is G0 x G0; L levels
     uint32_t gcells;           // total Gaussian cells over all levels
     uint32_t scells_cap;       // capacity (upper bound) of sample cells, multiple of 4
-    uint32_t ncounts;          // gcells + scells_cap
+    uint32_t sbase;            // index of the first sample-cell counter (gcells rounded up to a 128-B line)
+    uint32_t ncounts;          // sbase + scells_cap
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
-    size_t off_header, off_starts, off_cursor, off_blocksum, off_gkey, off_skey, off_rec, off_g2o, off_perm,
-        off_gacc, total_bytes;
+    uint32_t scan_blocks;      // workgroups of the scan = ceil((ncounts + 1) / PLAN_SCAN_BLOCK)
+    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_gkey, off_skey, off_rec, off_g2o, off_perm, off_gacc,
+        total_bytes;
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -74,17 +103,22 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.level_off[p.L] = off;
     p.gcells = off;
     // sample cells: <= M/target + perimeter slack, rounded to whole 2x2 blocks
-    int64_t cap = M / PLAN_POINTS_PER_CELL + 4 * (int64_t)(__builtin_sqrt((double)(M / PLAN_POINTS_PER_CELL + 1)) + 2) + 16;
+    int64_t cap = M / PLAN_POINTS_PER_CELL + 8 * (int64_t)(__builtin_sqrt((double)(M / PLAN_POINTS_PER_CELL + 1)) + 2) + 64;
     cap = (cap + 3) / 4 * 4;
     p.scells_cap = (uint32_t)cap;
-    p.ncounts = p.gcells + p.scells_cap;
+    p.sbase = (p.gcells + 31) / 32 * 32;
+    p.ncounts = p.sbase + p.scells_cap;
     size_t o = 0;
-    p.off_header = o;   o = align_up(o + sizeof(PlanHeader), 256);
-    p.off_starts = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)p.ncounts + 1), 256);
-    p.off_cursor = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)p.ncounts + 1), 256);
-    p.off_blocksum = o; o = align_up(o + sizeof(uint32_t) * ((size_t)p.ncounts / 4096 + 2), 256);
-    p.off_gkey = o;     o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
-    p.off_skey = o;     o = align_up(o + sizeof(uint32_t) * (size_t)M, 256);
+    p.scan_blocks = (p.ncounts + 1 + PLAN_SCAN_BLOCK - 1) / PLAN_SCAN_BLOCK;
+    p.off_params = o;   o = align_up(o + sizeof(PlanParams), 256);
+    p.off_boxes = o;    o = align_up(o + sizeof(BoxPartial) * PLAN_BBOX_BLOCKS, 256);
+    // counters and the scan's per-workgroup aggregates are adjacent: zeroed together
+    // (both arrays padded to whole scan blocks: the scan moves uint4s)
+    p.off_counts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
+    p.off_agg = o;      o = align_up(o + sizeof(uint64_t) * (size_t)p.scan_blocks, 256);
+    p.off_starts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
+    p.off_gkey = o;     o = align_up(o + sizeof(uint2) * (size_t)N, 256);      // {cell key, rank in cell}
+    p.off_skey = o;     o = align_up(o + sizeof(uint2) * (size_t)M, 256);
     p.off_rec = o;      o = align_up(o + 32 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
     p.off_perm = o;     o = align_up(o + sizeof(uint32_t) * (size_t)M, 256);
@@ -95,14 +129,15 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
 
 // Device view: raw pointers + the scalars kernels need.
 struct PlanView {
-    const PlanHeader* header;
-    const uint32_t* starts;       // [ncounts + 1] exclusive scan of counts; Gaussian cells then sample cells
+    const PlanParams* params;
+    const uint32_t* starts;       // [ncounts + 1] exclusive scan of the cell counters: Gaussian cells at
+                                  // [0, gcells), sample cells at [sbase, sbase + scells_cap)
     const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {c, v0, v1, v2}  (c <= 3)
     const uint32_t* g2o;          // sorted Gaussian -> original index
     const uint32_t* perm;         // sorted point -> original index
     uint32_t N, M;
     int G0, L;
-    uint32_t gcells, scells_cap;
+    uint32_t sbase, scells_cap;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     float q_max;
     float* gacc;                  // backward scratch: [8][N] sorted-order gradient sums
@@ -110,25 +145,10 @@ struct PlanView {
 
 // ---- grid geometry derived (identically by every thread) from the header's bounding boxes ----
 
-__host__ __device__ inline int32_t float_to_ordered(float f) {
-    int32_t i;
-    __builtin_memcpy(&i, &f, 4);
-    return i >= 0 ? i : i ^ 0x7fffffff;
-}
-__host__ __device__ inline float ordered_to_float(int32_t i) {
-    i = i >= 0 ? i : i ^ 0x7fffffff;
-    float f;
-    __builtin_memcpy(&f, &i, 4);
-    return f;
-}
-
-struct GaussGrid {
-    float ox, oy, inv_s0, s0;
-};
-__device__ inline GaussGrid gauss_grid(const PlanHeader* h, int G0) {
+// box = {min x, min y, max x, max y}; min > max (+-inf) when there were no finite points
+__device__ inline GaussGrid gauss_grid(const float* box, int G0) {
     GaussGrid g;
-    const float x0 = ordered_to_float(h->gbox[0]), y0 = ordered_to_float(h->gbox[1]);
-    const float x1 = ordered_to_float(h->gbox[2]), y1 = ordered_to_float(h->gbox[3]);
+    const float x0 = box[0], y0 = box[1], x1 = box[2], y1 = box[3];
     float ext = fmaxf(x1 - x0, y1 - y0);
     if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;      // empty / single point / non-finite
     g.ox = (x1 >= x0) ? x0 : 0.f;
@@ -138,14 +158,9 @@ __device__ inline GaussGrid gauss_grid(const PlanHeader* h, int G0) {
     return g;
 }
 
-struct SampleGrid {
-    float ox, oy, inv_w;
-    int nx, ny;   // even
-};
-__device__ inline SampleGrid sample_grid(const PlanHeader* h, uint32_t M, uint32_t scells_cap) {
+__device__ inline SampleGrid sample_grid(const float* box, uint32_t M, uint32_t scells_cap) {
     SampleGrid s;
-    const float x0 = ordered_to_float(h->sbox[0]), y0 = ordered_to_float(h->sbox[1]);
-    const float x1 = ordered_to_float(h->sbox[2]), y1 = ordered_to_float(h->sbox[3]);
+    const float x0 = box[0], y0 = box[1], x1 = box[2], y1 = box[3];
     float ex = x1 - x0, ey = y1 - y0;
     if (!(ex >= 0.f) || !(ex < 3.0e38f)) ex = 0.f;
     if (!(ey >= 0.f) || !(ey < 3.0e38f)) ey = 0.f;
@@ -156,7 +171,7 @@ __device__ inline SampleGrid sample_grid(const PlanHeader* h, uint32_t M, uint32
     s.ox = (x1 >= x0) ? x0 : 0.f;
     s.oy = (y1 >= y0) ? y0 : 0.f;
     float w = sqrtf(ex * ey * (float)PLAN_POINTS_PER_CELL / (float)(M > 0 ? M : 1));
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 16; ++it) {
         s.nx = ((int)ceilf(ex / w) + 1) & ~1;
         s.ny = ((int)ceilf(ey / w) + 1) & ~1;
         if (s.nx < 2) s.nx = 2;
