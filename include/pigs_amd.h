@@ -89,11 +89,10 @@ int pigs_plan_build(void* workspace, size_t workspace_bytes, void* scratch, int6
                     const void* samples, void* stream);
 
 int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                      int orders_mask, const void* samples,
-                      void* out0, void* out1, void* out2, void* out3, void* stream);
+                      int orders_mask, void* out0, void* out1, void* out2, void* out3, void* stream);
 
 int pigs_plan_backward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                       int orders_mask, const void* samples,
+                       int orders_mask,
                        const void* gout0, const void* gout1, const void* gout2, const void* gout3,
                        void* g_means, void* g_conics, void* g_values, void* stream);
 

@@ -25,8 +25,8 @@ SIGNATURES = {
     "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
     "pigs_plan_scratch_bytes": (ctypes.c_size_t, []),
     "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _vp, _i64, _i64, _i, ctypes.c_float] + [_vp] * 4 + [_vp]),
-    "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i, _vp] + [_vp] * 4 + [_vp]),
-    "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i, _vp] + [_vp] * 4
+    "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4 + [_vp]),
+    "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4
                            + [_vp] * 3 + [_vp]),
 }
 

@@ -13,7 +13,38 @@
 #include "plan.h"
 #include "launch.h"
 
+#ifndef PIGS_FWD_WAVES
+#define PIGS_FWD_WAVES 6   // waves per SIMD the forward kernel's register budget is held to
+#endif
+#ifndef PIGS_STAMPS
+#define PIGS_STAMPS 0   // diagnostic build: per-wave s_memtime stamps of the forward kernel phases
+#endif
+#ifndef PIGS_FWD_BLOCK_WAVES
+#define PIGS_FWD_BLOCK_WAVES 4   // waves (= sample cells) per forward workgroup; divides 4
+#endif
+#ifndef PIGS_FWD_UNROLL
+#define PIGS_FWD_UNROLL 2     // accepted records evaluated per loop iteration
+#endif
+#ifndef PIGS_FWD_TRAVERSE
+#define PIGS_FWD_TRAVERSE 1   // 0: per-level/row loops with their own loads; 1: batched ranges (traverse())
+#endif
+#ifndef PIGS_ABLATE
+#define PIGS_ABLATE 0   // timing-only ablation builds (tools/ablate.sh); 0 in the product
+#endif
+
+
 namespace pigs {
+
+#if PIGS_STAMPS
+__device__ unsigned long long g_stamps[32768][6];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes, all active)
@@ -66,7 +97,7 @@ struct BuildArgs {
     uint2* skey;          // per point    {cell id,  rank inside the cell}
     float4* rec;
     uint32_t* g2o;
-    uint32_t* perm;
+    SPoint* spts;
     const float* means;
     const float* conics;
     const float* values;
@@ -304,7 +335,10 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     }
     if (i < a.M) {
         const uint2 kr = a.skey[i];
-        a.perm[a.starts[a.sbase + kr.x] - a.N + kr.y] = i;
+        const float2 p = ((const float2*)a.samples)[i];
+        SPoint sp;
+        sp.x = p.x; sp.y = p.y; sp.m = i;
+        a.spts[a.starts[a.sbase + kr.x] - a.N + kr.y] = sp;
     }
 }
 
@@ -331,11 +365,19 @@ __device__ __forceinline__ bool ellipse_reaches_rect(float4 A, float cc, float x
 // wave-uniform) for every Gaussian whose ellipse reaches the box, and `batch_begin(j0)` /
 // `batch_end(j0, mask)` around each step of 64 candidates.
 // ------------------------------------------------------------------------------------------
-template <typename BatchBegin, typename Visit, typename BatchEnd>
-__device__ __forceinline__ void for_each_reaching_gaussian(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask,
-                                                           float bx0, float by0, float bx1, float by1, int lane,
-                                                           BatchBegin&& batch_begin, Visit&& visit,
-                                                           BatchEnd&& batch_end) {
+// ------------------------------------------------------------------------------------------
+// the traversal shared by forward and backward: per occupied level, the contiguous record ranges
+// of the cells within one cell of the box; 64 candidates per step (one per lane), tested
+// exactly; `step(j0, A, B, mask)` receives the step's first sorted index, this lane's record and
+// the ballot of accepted lanes.
+// ------------------------------------------------------------------------------------------
+template <typename Step>
+__device__ __forceinline__ void for_each_candidate_step(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask,
+                                                        float bx0, float by0, float bx1, float by1, int lane,
+                                                        Step&& step) {
+#if PIGS_ABLATE == 3
+    return;
+#endif
     for (int l = 0; l < pv.L; ++l) {
         if (!(level_mask >> l & 1u)) continue;
         const int G = pv.G0 >> l;
@@ -356,73 +398,250 @@ __device__ __forceinline__ void for_each_reaching_gaussian(const PlanView& pv, c
                 const uint32_t jj = ok ? j : jb;
                 const float4 A = pv.rec[2 * jj];
                 const float4 B = pv.rec[2 * jj + 1];
+#if PIGS_ABLATE == 2
+                asm volatile("" ::"v"(A.x), "v"(B.x));
+                ok = false;
+#else
                 ok = ok && ellipse_reaches_rect(A, B.x, bx0, by0, bx1, by1, pv.q_max);
-                uint64_t mask = __ballot(ok);
-                batch_begin(j0);
-                uint64_t rest = mask;
-                while (rest) {
-                    const int b = __builtin_ctzll(rest);
-                    rest &= rest - 1;
-                    visit(j0 + (uint32_t)b, b);
-                }
-                batch_end(j0, mask);
+#endif
+                const uint64_t mask = __ballot(ok);
+                if (mask) step(j0, A, B, mask);
             }
         }
     }
 }
 
-// scalar-path record fetch (j is wave-uniform)
 struct Rec {
     float mu[2], con[3], v[3];
 };
-__device__ __forceinline__ Rec load_rec(const float4* __restrict__ rec, uint32_t j) {
-    const float4 A = rec[2 * j], B = rec[2 * j + 1];
+__device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
     Rec r;
     r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.x;
     r.v[0] = B.y; r.v[1] = B.z; r.v[2] = B.w;
     return r;
 }
+// scalar-path record fetch (j is wave-uniform)
+__device__ __forceinline__ Rec load_rec(const float4* __restrict__ rec, uint32_t j) {
+    return make_rec(rec[2 * j], rec[2 * j + 1]);
+}
+
+__device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mask below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward: one wave per sample cell (lane = point), lean on VALU issue slots (the kernel is
+// bound by them, ~1.2 ns per wave-instruction per SIMD) and on dependent memory round trips:
+//   1. cell bounds (scalar loads) -> the cell's sorted points (one 12-byte load per lane)
+//   2. bounding box of the points (DPP min/max)
+//   3. per-level cell rectangles computed lane-parallel (lane = level), their rows scattered
+//      into an LDS table, then ONE gather fetches every row's record range
+//   4. rows walked in wave-uniform order, 64 candidates per step; the next step's records are
+//      in flight while the current step is tested exactly against the box
+//   5. accepted records (already in registers) are compacted into a wave-private LDS queue and
+//      evaluated from there with wave-uniform addresses (LDS broadcast -> VGPR operands; an
+//      SGPR operand makes a VALU op ~1.6x slower on gfx950), two per iteration, the next two
+//      prefetched
+//   6. outputs stored through the point's original index.
+// ------------------------------------------------------------------------------------------
+constexpr int QCAP = 128;   // accepted records queued per wave before an evaluation run
+
+struct WaveLds {
+    float4 queue[QCAP + 2 * PIGS_FWD_UNROLL][2];
+    uint32_t row_a0[64];
+    uint32_t row_a1[64];
+};
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_keep_f32(float v) {     // lanes without a source keep v
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_min_dpp(float v) {
+    v = fminf(v, dpp_keep_f32<0xB1>(v));
+    v = fminf(v, dpp_keep_f32<0x4E>(v));
+    v = fminf(v, dpp_keep_f32<0x141>(v));
+    v = fminf(v, dpp_keep_f32<0x140>(v));
+    v = fminf(v, dpp_keep_f32<0x142, 0xA>(v));
+    v = fminf(v, dpp_keep_f32<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) { return -wave_min_dpp(-v); }
 
 template <int C, int MASK>
-__global__ __launch_bounds__(256) void binned_forward_kernel(PlanView pv, const float* __restrict__ samples,
-                                                             float* __restrict__ o0, float* __restrict__ o1,
-                                                             float* __restrict__ o2, float* __restrict__ o3) {
+__device__ __forceinline__ void evaluate_queue(float* acc, const float* s, float4 (*q)[2], int n, int lane) {
+    constexpr int U = PIGS_FWD_UNROLL;       // records per iteration (independent chains for ILP)
+    if (n == 0) return;
+    if (lane < 2 * U - 1) {   // neutral records (v = 0) behind the last one: ragged n and the prefetch
+        q[n + lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q[n + lane][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { a[u] = q[u][0]; b[u] = q[u][1]; }
+    for (int k = 0; k < n; k += U) {
+        float4 na[U], nb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { na[u] = q[k + U + u][0]; nb[u] = q[k + U + u][1]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Rec r = make_rec(a[u], b[u]);
+            fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = na[u]; b[u] = nb[u]; }
+    }
+}
+
+// Steps 3-4 for one pass.  `batch(A, B, mask, j)` is called for every step with accepted
+// candidates (A, B: this lane's record; j: its sorted Gaussian index).
+template <typename Batch>
+__device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask, float bx0,
+                                         float by0, float bx1, float by1, int lane, WaveLds& lds, Batch&& batch) {
+    // 3. lane = level: rectangle of cells within one cell of the box; rows scanned over lanes
+    const bool occ = lane < pv.L && (level_mask >> lane & 1u);
+    const int sh = lane < pv.L ? lane : 0;
+    const int G = pv.G0 >> sh;
+    const float inv_s = gg.inv_s0 * __builtin_amdgcn_ldexpf(1.f, -sh);
+    const float gmax = (float)(G - 1);
+    const int cx0 = (int)clampf(floorf((bx0 - gg.ox) * inv_s) - 1.f, 0.f, gmax);
+    const int cx1 = (int)clampf(floorf((bx1 - gg.ox) * inv_s) + 1.f, 0.f, gmax);
+    const int cy0 = (int)clampf(floorf((by0 - gg.oy) * inv_s) - 1.f, 0.f, gmax);
+    const int cy1 = (int)clampf(floorf((by1 - gg.oy) * inv_s) + 1.f, 0.f, gmax);
+    const int nr = occ ? cy1 - cy0 + 1 : 0;
+    // first cell of level l = sum_{k<l} (G0 >> k)^2 = 4 (G0^2 - (G0 >> l)^2) / 3   (G0 a power of two)
+    const uint32_t loff = (uint32_t)(4 * (pv.G0 * pv.G0 - G * G) / 3);
+    int inc = nr;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {           // levels live in lanes 0..11
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    const int cum = inc - nr;
+    const int R = __builtin_amdgcn_readlane(inc, 15);
+
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        for (int k = 0; k < nr; ++k) {
+            const int r = cum + k - r0;
+            if (r >= 0 && r < 64) {
+                const uint32_t row = loff + (uint32_t)((cy0 + k) * G);
+                lds.row_a0[r] = row + (uint32_t)cx0;
+                lds.row_a1[r] = row + (uint32_t)cx1 + 1u;
+            }
+        }
+        const int nrow = R - r0 < 64 ? R - r0 : 64;
+        uint32_t jbv = 0, lenv = 0;
+        if (lane < nrow) {
+            jbv = pv.starts[lds.row_a0[lane]];
+            lenv = pv.starts[lds.row_a1[lane]] - jbv;
+        }
+        // 4. wave-uniform walk over the rows' ranges, one step (64 candidates) ahead
+        int r = -1;
+        uint32_t j0 = 0, je = 0;
+        auto advance = [&]() -> bool {
+            j0 += 64;
+            while (j0 >= je) {
+                if (++r >= nrow) return false;
+                j0 = (uint32_t)__builtin_amdgcn_readlane((int)jbv, r);
+                je = j0 + (uint32_t)__builtin_amdgcn_readlane((int)lenv, r);
+            }
+            return true;
+        };
+        bool have = advance();
+        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+        uint32_t j = 0;
+        bool in = false;
+        if (have) {
+            j = j0 + lane;
+            in = j < je;
+            if (!in) j = j0;
+            A = pv.rec[2 * j];
+            B = pv.rec[2 * j + 1];
+        }
+        while (have) {
+            have = advance();
+            float4 An = A, Bn = B;
+            uint32_t jn = 0;
+            bool inn = false;
+            if (have) {
+                jn = j0 + lane;
+                inn = jn < je;
+                if (!inn) jn = j0;
+                An = pv.rec[2 * jn];
+                Bn = pv.rec[2 * jn + 1];
+            }
+            const bool ok = in && ellipse_reaches_rect(A, B.x, bx0, by0, bx1, by1, pv.q_max);
+            const uint64_t mask = __ballot(ok);
+            if (mask) batch(A, B, mask, j);
+            A = An; B = Bn; j = jn; in = inn;
+        }
+    }
+}
+
+template <int C, int MASK>
+__global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void binned_forward_kernel(
+    PlanView pv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3) {
     using L = FwdLayout<2, C, MASK>;
+    __shared__ WaveLds lds_all[PIGS_FWD_BLOCK_WAVES];
     const int lane = threadIdx.x & 63;
-    const uint32_t cell = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
-    const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
-    if (sbeg >= send) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLds& lds = lds_all[wave];
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
     const float INF = __builtin_huge_valf();
-
+    const uint32_t cell = blockIdx.x * PIGS_FWD_BLOCK_WAVES + (uint32_t)wave;
+    const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
+    const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
+#if PIGS_STAMPS
+    const unsigned long long T0 = stamp();
+#endif
     for (uint32_t base = sbeg; base < send; base += 64) {
-        const uint32_t i = base + lane;
-        const bool valid = i < send;
-        const uint32_t m = valid ? pv.perm[i] : 0u;
-        float s[2] = {0.f, 0.f};
-        if (valid) {
-            const float2 p = ((const float2*)samples)[m];
-            s[0] = p.x; s[1] = p.y;
-        }
-        const float bx0 = wave_min_bcast(valid ? s[0] : INF), bx1 = wave_max_bcast(valid ? s[0] : -INF);
-        const float by0 = wave_min_bcast(valid ? s[1] : INF), by1 = wave_max_bcast(valid ? s[1] : -INF);
+        const bool valid = base + lane < send;
+        SPoint sp = {0.f, 0.f, 0u};
+        if (valid) sp = pv.spts[base + lane];
+        float s[2] = {sp.x, sp.y};
+        const float bx0 = wave_min_dpp(valid ? s[0] : INF), bx1 = wave_max_dpp(valid ? s[0] : -INF);
+        const float by0 = wave_min_dpp(valid ? s[1] : INF), by1 = wave_max_dpp(valid ? s[1] : -INF);
         if (!valid) { s[0] = bx0; s[1] = by0; }
 
         float acc[L::N];
 #pragma unroll
         for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
-
-        for_each_reaching_gaussian(
-            pv, gg, level_mask, bx0, by0, bx1, by1, lane, [](uint32_t) {},
-            [&](uint32_t j, int) {
-                const Rec r = load_rec(pv.rec, j);
-                fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v);
-            },
-            [](uint32_t, uint64_t) {});
-
-        if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)m, o0, o1, o2, o3);
+        int qn = 0;
+#if PIGS_STAMPS
+        const unsigned long long T1 = stamp();
+#endif
+#if PIGS_FWD_TRAVERSE == 0
+        for_each_candidate_step(pv, gg, level_mask, bx0, by0, bx1, by1, lane,
+                 [&](uint32_t, const float4 A, const float4 B, uint64_t mask) {
+#else
+        traverse(pv, gg, level_mask, bx0, by0, bx1, by1, lane, lds,
+                 [&](const float4 A, const float4 B, uint64_t mask, uint32_t) {
+#endif
+            const int cnt = __builtin_popcountll(mask);
+            if (qn + cnt > QCAP) {
+                evaluate_queue<C, MASK>(acc, s, lds.queue, qn, lane);
+                qn = 0;
+            }
+            const int slot = qn + lanes_below(mask);
+            if (mask >> lane & 1ull) { lds.queue[slot][0] = A; lds.queue[slot][1] = B; }
+            qn += cnt;
+        });
+#if PIGS_STAMPS
+        const unsigned long long T2 = stamp();
+#endif
+        evaluate_queue<C, MASK>(acc, s, lds.queue, qn, lane);
+#if PIGS_STAMPS
+        const unsigned long long T3 = stamp();
+#endif
+        if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+#if PIGS_STAMPS
+        const unsigned long long T4 = stamp();
+        if (lane == 0 && cell < 32768) {
+            g_stamps[cell][0] = T0; g_stamps[cell][1] = T1; g_stamps[cell][2] = T2; g_stamps[cell][3] = T3;
+            g_stamps[cell][4] = T4; g_stamps[cell][5] = (unsigned long long)qn;
+        }
+#endif
     }
 }
 
@@ -431,8 +650,7 @@ __global__ __launch_bounds__(256) void binned_forward_kernel(PlanView pv, const 
 // those lanes add their 5+c sums to the sorted-order scratch gacc[k][j] (consecutive lanes ->
 // consecutive addresses).  plan_unpermute_kernel then writes the caller's gradient layout.
 template <int C, int MASK>
-__global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const float* __restrict__ samples,
-                                                              const float* __restrict__ G0p,
+__global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const float* __restrict__ G0p,
                                                               const float* __restrict__ G1p,
                                                               const float* __restrict__ G2p,
                                                               const float* __restrict__ G3p) {
@@ -449,11 +667,11 @@ __global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const
     for (uint32_t base = sbeg; base < send; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < send;
-        const uint32_t m = valid ? pv.perm[i] : 0u;
+        uint32_t m = 0u;
         float s[2] = {0.f, 0.f};
         if (valid) {
-            const float2 p = ((const float2*)samples)[m];
-            s[0] = p.x; s[1] = p.y;
+            const SPoint sp = pv.spts[i];
+            s[0] = sp.x; s[1] = sp.y; m = sp.m;
         }
         const float bx0 = wave_min_bcast(valid ? s[0] : INF), bx1 = wave_max_bcast(valid ? s[0] : -INF);
         const float by0 = wave_min_bcast(valid ? s[1] : INF), by1 = wave_max_bcast(valid ? s[1] : -INF);
@@ -471,15 +689,16 @@ __global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const
             }
         }
 
-        float mine[BL::N];
-        for_each_reaching_gaussian(
-            pv, gg, level_mask, bx0, by0, bx1, by1, lane,
-            [&](uint32_t) {
+        for_each_candidate_step(pv, gg, level_mask, bx0, by0, bx1, by1, lane,
+                                [&](uint32_t j0, const float4, const float4, uint64_t mask) {
+            float mine[BL::N];
 #pragma unroll
-                for (int k = 0; k < BL::N; ++k) mine[k] = 0.f;
-            },
-            [&](uint32_t j, int b) {
-                const Rec r = load_rec(pv.rec, j);
+            for (int k = 0; k < BL::N; ++k) mine[k] = 0.f;
+            uint64_t rest = mask;
+            while (rest) {
+                const int b = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                const Rec r = load_rec(pv.rec, j0 + (uint32_t)b);
                 float part[BL::N];
 #pragma unroll
                 for (int k = 0; k < BL::N; ++k) part[k] = 0.f;
@@ -489,13 +708,12 @@ __global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const
                     const float tot = wave_sum_bcast(part[k]);
                     mine[k] = (lane == b) ? tot : mine[k];
                 }
-            },
-            [&](uint32_t j0, uint64_t mask) {
-                if (mask >> lane & 1ull) {
+            }
+            if (mask >> lane & 1ull) {
 #pragma unroll
-                    for (int k = 0; k < BL::N; ++k) atomicAdd(&pv.gacc[(size_t)k * pv.N + j0 + lane], mine[k]);
-                }
-            });
+                for (int k = 0; k < BL::N; ++k) atomicAdd(&pv.gacc[(size_t)k * pv.N + j0 + lane], mine[k]);
+            }
+        });
     }
 }
 
@@ -525,7 +743,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     v.starts = (const uint32_t*)(b + p.off_starts);
     v.rec = (const float4*)(b + p.off_rec);
     v.g2o = (const uint32_t*)(b + p.off_g2o);
-    v.perm = (const uint32_t*)(b + p.off_perm);
+    v.spts = (const SPoint*)(b + p.off_spts);
     v.N = (uint32_t)p.N; v.M = (uint32_t)p.M;
     v.G0 = p.G0; v.L = p.L;
     v.sbase = p.sbase; v.scells_cap = p.scells_cap;
@@ -541,6 +759,12 @@ static bool plan_supported(int64_t N, int64_t M, int c) {
 }
 
 size_t plan_scratch_bytes() { return PLAN_SCRATCH_BYTES; }
+
+#if PIGS_STAMPS
+extern "C" int pigs_debug_stamps(void* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32768 * 6);
+}
+#endif
 
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
     if (!plan_supported(N, M, c)) return 0;
@@ -566,7 +790,7 @@ int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, i
     a.skey = (uint2*)(b + p.off_skey);
     a.rec = (float4*)(b + p.off_rec);
     a.g2o = (uint32_t*)(b + p.off_g2o);
-    a.perm = (uint32_t*)(b + p.off_perm);
+    a.spts = (SPoint*)(b + p.off_spts);
     a.means = (const float*)means; a.conics = (const float*)conics;
     a.values = (const float*)values; a.samples = (const float*)samples;
     a.N = (uint32_t)N; a.M = (uint32_t)M; a.c = c; a.G0 = p.G0; a.L = p.L;
@@ -586,13 +810,13 @@ int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, i
 }
 
 template <int C>
-static int plan_forward_c(const PlanView& pv, int mask, const float* samples, float* const* out, hipStream_t stream) {
-    const dim3 grid(pv.scells_cap / 4), block(256);
+static int plan_forward_c(const PlanView& pv, int mask, float* const* out, hipStream_t stream) {
+    const dim3 grid(pv.scells_cap / PIGS_FWD_BLOCK_WAVES), block(64 * PIGS_FWD_BLOCK_WAVES);
     clear_hip_error();
 #define PIGS_CASE(MK)                                                                                        \
     case MK:                                                                                                 \
-        hipLaunchKernelGGL((binned_forward_kernel<C, MK>), grid, block, 0, stream, pv, samples, out[0], out[1], \
-                           out[2], out[3]);                                                                  \
+        hipLaunchKernelGGL((binned_forward_kernel<C, MK>), grid, block, 0, stream, pv, out[0], out[1], out[2], \
+                           out[3]);                                                                          \
         break;
     switch (mask) {
         PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15)
@@ -603,15 +827,14 @@ static int plan_forward_c(const PlanView& pv, int mask, const float* samples, fl
 }
 
 template <int C>
-static int plan_backward_c(const PlanView& pv, int mask, const float* samples, const float* const* g, float* gm,
-                           float* gc, float* gv, hipStream_t stream) {
+static int plan_backward_c(const PlanView& pv, int mask, const float* const* g, float* gm, float* gc, float* gv,
+                           hipStream_t stream) {
     const dim3 grid(pv.scells_cap / 4), block(256);
     clear_hip_error();
     if (hipMemsetAsync(pv.gacc, 0, sizeof(float) * 8 * (size_t)pv.N, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
 #define PIGS_CASE(MK)                                                                                         \
     case MK:                                                                                                  \
-        hipLaunchKernelGGL((binned_backward_kernel<C, MK>), grid, block, 0, stream, pv, samples, g[0], g[1], g[2], \
-                           g[3]);                                                                             \
+        hipLaunchKernelGGL((binned_backward_kernel<C, MK>), grid, block, 0, stream, pv, g[0], g[1], g[2], g[3]); \
         break;
     switch (mask) {
         PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15)
@@ -628,8 +851,8 @@ static int covering_mask_b(int mask) {
     return 15;
 }
 
-int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask,
-                 const void* samples, void* const* out, hipStream_t stream) {
+int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask, void* const* out,
+                 hipStream_t stream) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
     const PlanLayout p = make_plan_layout(N, M, c);
     if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
@@ -638,16 +861,15 @@ int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q
     for (int k = 0; k < 4; ++k) o[k] = (mask >> k & 1) ? (float*)out[k] : nullptr;
     const int cm = covering_mask_b(mask);
     switch (c) {
-        case 1: return plan_forward_c<1>(pv, cm, (const float*)samples, o, stream);
-        case 2: return plan_forward_c<2>(pv, cm, (const float*)samples, o, stream);
-        case 3: return plan_forward_c<3>(pv, cm, (const float*)samples, o, stream);
+        case 1: return plan_forward_c<1>(pv, cm, o, stream);
+        case 2: return plan_forward_c<2>(pv, cm, o, stream);
+        case 3: return plan_forward_c<3>(pv, cm, o, stream);
     }
     return PIGS_ERR_UNSUPPORTED;
 }
 
 int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask,
-                  const void* samples, const void* const* gout, void* g_means, void* g_conics, void* g_values,
-                  hipStream_t stream) {
+                  const void* const* gout, void* g_means, void* g_conics, void* g_values, hipStream_t stream) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
     const PlanLayout p = make_plan_layout(N, M, c);
     if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
@@ -656,9 +878,9 @@ int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float 
     for (int k = 0; k < 4; ++k) g[k] = (mask >> k & 1) ? (const float*)gout[k] : nullptr;
     const int cm = covering_mask_b(mask);
     switch (c) {
-        case 1: return plan_backward_c<1>(pv, cm, (const float*)samples, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
-        case 2: return plan_backward_c<2>(pv, cm, (const float*)samples, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
-        case 3: return plan_backward_c<3>(pv, cm, (const float*)samples, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
+        case 1: return plan_backward_c<1>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
+        case 2: return plan_backward_c<2>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
+        case 3: return plan_backward_c<3>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
     }
     return PIGS_ERR_UNSUPPORTED;
 }

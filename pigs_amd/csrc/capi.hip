@@ -75,27 +75,24 @@ int pigs_plan_build(void* workspace, size_t workspace_bytes, void* scratch, int6
 }
 
 int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                      int orders_mask, const void* samples, void* out0, void* out1, void* out2, void* out3,
-                      void* stream) {
-    if (orders_mask <= 0 || orders_mask > 15 || !samples) return PIGS_ERR_INVALID;
+                      int orders_mask, void* out0, void* out1, void* out2, void* out3, void* stream) {
+    if (orders_mask <= 0 || orders_mask > 15) return PIGS_ERR_INVALID;
     void* outs[4] = {out0, out1, out2, out3};
     for (int k = 0; k < 4; ++k)
         if ((orders_mask >> k & 1) && !outs[k]) return PIGS_ERR_INVALID;
-    return plan_forward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, samples, outs,
-                        (hipStream_t)stream);
+    return plan_forward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, outs, (hipStream_t)stream);
 }
 
 int pigs_plan_backward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                       int orders_mask, const void* samples, const void* gout0, const void* gout1,
-                       const void* gout2, const void* gout3, void* g_means, void* g_conics, void* g_values,
-                       void* stream) {
-    if (orders_mask <= 0 || orders_mask > 15 || !samples) return PIGS_ERR_INVALID;
+                       int orders_mask, const void* gout0, const void* gout1, const void* gout2,
+                       const void* gout3, void* g_means, void* g_conics, void* g_values, void* stream) {
+    if (orders_mask <= 0 || orders_mask > 15) return PIGS_ERR_INVALID;
     const void* gs[4] = {gout0, gout1, gout2, gout3};
     for (int k = 0; k < 4; ++k)
         if ((orders_mask >> k & 1) && !gs[k]) return PIGS_ERR_INVALID;
     if (!g_means || !g_conics || !g_values) return PIGS_ERR_INVALID;
-    return plan_backward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, samples, gs, g_means, g_conics,
-                         g_values, (hipStream_t)stream);
+    return plan_backward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, gs, g_means, g_conics, g_values,
+                         (hipStream_t)stream);
 }
 
 }  // extern "C"

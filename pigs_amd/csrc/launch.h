@@ -24,11 +24,10 @@ size_t plan_scratch_bytes();
 int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, int c, float q_max,
                const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream);
-int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask,
-                 const void* samples, void* const* out, hipStream_t stream);
+int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask, void* const* out,
+                 hipStream_t stream);
 int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask,
-                  const void* samples, const void* const* gout, void* g_means, void* g_conics, void* g_values,
-                  hipStream_t stream);
+                  const void* const* gout, void* g_means, void* g_conics, void* g_values, hipStream_t stream);
 
 // The HIP "last error" is sticky per thread and the host process (PyTorch) makes its own HIP
 // calls: clear it before a launch, read it after.

@@ -12,8 +12,8 @@
 //    of packed 32-byte records: the cells within one cell of the rectangle, per level.
 //    Memory is static (N records + the cell table): no per-call allocation, no host sync.
 //  * Sample points are counting-sorted into square cells holding ~63 points (2x2-blocked cell
-//    order, so the four waves of a workgroup own a 2x2 block of cells); `perm` maps sorted
-//    position -> original point index.  One wave = one cell = 64 lanes = 64 points.
+//    order, so the four waves of a workgroup own a 2x2 block of cells); the sorted copy keeps
+//    each point's original index.  One wave = one cell = 64 lanes = 64 points.
 //
 // Cut-off: a (point, Gaussian) pair is evaluated iff the Gaussian's ellipse q <= q_max reaches
 // the bounding box of the wave's points (exact ellipse/rectangle test).  Dropped terms are
@@ -59,6 +59,12 @@ struct SampleGrid {
     float ox, oy, inv_w;
     int nx, ny;   // even
 };
+// A sample point in sorted (cell) order: its coordinates and its index in the caller's array.
+struct SPoint {
+    float x, y;
+    uint32_t m;
+};
+
 // Written once by the build (first bytes of the workspace), read by the sampling kernels.
 struct PlanParams {
     GaussGrid gg;
@@ -79,7 +85,7 @@ struct PlanLayout {
     uint32_t ncounts;          // sbase + scells_cap
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     uint32_t scan_blocks;      // workgroups of the scan = ceil((ncounts + 1) / PLAN_SCAN_BLOCK)
-    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_gkey, off_skey, off_rec, off_g2o, off_perm, off_gacc,
+    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_gkey, off_skey, off_rec, off_g2o, off_spts, off_gacc,
         total_bytes;
 };
 
@@ -104,7 +110,7 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.gcells = off;
     // sample cells: <= M/target + perimeter slack, rounded to whole 2x2 blocks
     int64_t cap = M / PLAN_POINTS_PER_CELL + 8 * (int64_t)(__builtin_sqrt((double)(M / PLAN_POINTS_PER_CELL + 1)) + 2) + 64;
-    cap = (cap + 3) / 4 * 4;
+    cap = (cap + 3) / 4 * 4;         // whole 2x2 blocks
     p.scells_cap = (uint32_t)cap;
     p.sbase = (p.gcells + 31) / 32 * 32;
     p.ncounts = p.sbase + p.scells_cap;
@@ -121,7 +127,7 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_skey = o;     o = align_up(o + sizeof(uint2) * (size_t)M, 256);
     p.off_rec = o;      o = align_up(o + 32 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
-    p.off_perm = o;     o = align_up(o + sizeof(uint32_t) * (size_t)M, 256);
+    p.off_spts = o;     o = align_up(o + sizeof(SPoint) * (size_t)M, 256);
     p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [8][N]
     p.total_bytes = o;
     return p;
@@ -134,7 +140,7 @@ struct PlanView {
                                   // [0, gcells), sample cells at [sbase, sbase + scells_cap)
     const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {c, v0, v1, v2}  (c <= 3)
     const uint32_t* g2o;          // sorted Gaussian -> original index
-    const uint32_t* perm;         // sorted point -> original index
+    const SPoint* spts;           // sorted points: coordinates + original index
     uint32_t N, M;
     int G0, L;
     uint32_t sbase, scells_cap;

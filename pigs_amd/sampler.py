@@ -86,8 +86,8 @@ def forward_raw(means, values, conics, samples, mask, plan=None):
         with torch.cuda.device(means.device):
             if plan is not None:
                 rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
-                                           _ptr(samples), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
-                                           _ptr(outs[3]), _stream(means.device))
+                                           _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]),
+                                           _stream(means.device))
                 _lib.check(rc, "pigs_plan_forward")
             else:
                 rc = lib.pigs_sample_forward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
@@ -111,7 +111,7 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
         with torch.cuda.device(means.device):
             if plan is not None and M > 0:
                 rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
-                                            _ptr(samples), _ptr(gouts[0]), _ptr(gouts[1]), _ptr(gouts[2]),
+                                            _ptr(gouts[0]), _ptr(gouts[1]), _ptr(gouts[2]),
                                             _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics), _ptr(g_values),
                                             _stream(means.device))
                 _lib.check(rc, "pigs_plan_backward")
