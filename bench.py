@@ -43,6 +43,19 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(workload, kappa, binned):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command, corrected as MI355X_MICROARCH.md 'HBM' prescribes); None when no profile of
+    this exact configuration is committed."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        key = f"{workload}:kappa={kappa}:{'binned' if binned else 'dense'}"
+        return table.get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
     """Cores this process may actually use: affinity, capped by the cgroup CPU quota and by the
     GPU box's per-GPU share (16)."""
@@ -155,7 +168,7 @@ def main():
     algo_bytes = 24 * N + 36 * M       # fp32, d=2, c=1: 6 floats/Gaussian + (2 in + 7 out) floats/point
     achieved = algo_bytes / kernel_s
     roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
+                "frac": achieved / HBM_PEAK, "traffic": measured_traffic(a.workload, a.kappa, plan is not None),
                 "kernel": ("binned_forward_kernel<1,7>" if plan is not None else "dense_forward_kernel<float,2,1,7,4>"),
                 "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": algo_bytes}
     if plan is None:
@@ -166,16 +179,16 @@ def main():
     if not a.no_bwd:
         req = {k: t[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
 
+        from pigs_amd.distributed import replicated
+
         def train_step():
-            sampler.preprocess(req["means"], req["values"], t["covariances"], req["conics"], pts_d)
+            # parameter grads are summed over the ranks by ONE all-reduce of a packed [N,6] buffer
+            m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
+            sampler.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
             u, ux, uxx = sampler.sample((0, 1, 2))
             # diffusion residual shape of test_no_mlp.py:144 (u_t replaced by u: same data flow)
             loss = ((u[:, 0] - (uxx[:, 0, 0, 0] + uxx[:, 1, 1, 0])) ** 2).mean() + (ux ** 2).mean()
-            grads = torch.autograd.grad(loss, list(req.values()))
-            if dist is not None:
-                flat = torch.cat([g.reshape(N, -1) for g in grads], dim=1)   # one [N,6] buffer, one all-reduce
-                dist.all_reduce(flat)
-            return grads
+            return torch.autograd.grad(loss, list(req.values()))
 
         nb = max(1, min(a.steps, 3 if a.workload == "c3" else 10))
         train_step()
