@@ -25,6 +25,9 @@
 #ifndef PIGS_FWD_UNROLL
 #define PIGS_FWD_UNROLL 2     // accepted records evaluated per loop iteration
 #endif
+#ifndef PIGS_BWD_WAVES
+#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to
+#endif
 #ifndef PIGS_FWD_TRAVERSE
 #define PIGS_FWD_TRAVERSE 1   // 0: per-level/row loops with their own loads; 1: batched ranges (traverse())
 #endif
@@ -447,7 +450,7 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mas
 constexpr int QCAP = 128;   // accepted records queued per wave before an evaluation run
 
 struct WaveLds {
-    float4 queue[QCAP + 2 * PIGS_FWD_UNROLL][2];
+    float4 queue[QCAP + 8][2];
     uint32_t row_a0[64];
     uint32_t row_a1[64];
 };
@@ -645,40 +648,117 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void bin
     }
 }
 
-// Backward: same traversal.  For every accepted Gaussian the per-point contributions are summed
-// over the 64 lanes (DPP) and parked in the lane that tested that candidate; after the step
-// those lanes add their 5+c sums to the sorted-order scratch gacc[k][j] (consecutive lanes ->
-// consecutive addresses).  plan_unpermute_kernel then writes the caller's gradient layout.
+// ------------------------------------------------------------------------------------------
+// Backward: same cell / traversal / LDS queue as the forward.  Every (wave, Gaussian) row yields
+// NV = 5 + c per-lane contributions that must be summed over the 64 points.  Rows are processed
+// eight at a time and reduced by a transposing butterfly (v_permlane32_swap, v_permlane16_swap,
+// then 4 DPP steps inside a row): 2.5 NV instructions per Gaussian instead of 6 NV for eight
+// separate wave reductions.  The sums are parked in LDS by queue slot and flushed with one atomic
+// per lane and value into gacc[k][j] (queue order follows the sorted order, so consecutive lanes
+// hit near-consecutive addresses); plan_unpermute_kernel writes the caller's layout.
+// ------------------------------------------------------------------------------------------
+struct WaveLdsBwd {
+    WaveLds t;                    // queue + row tables (shared code with the forward)
+    uint32_t qj[QCAP + 8];        // sorted Gaussian index of every queue slot
+    float sums[QCAP + 8][8];      // per-slot reduced contributions
+};
+
+// hipcc (ROCm 7.2) mis-lowers __builtin_amdgcn_permlane{32,16}_swap when both results feed one
+// add (it emits v_add v, v, v with the FIRST result twice), so the swaps are inline asm.  The
+// s_nop covers the VALU-write -> permlane-swap-read wait states the compiler would insert.
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;     // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;     // rows 0,2: a[row] + a[row+1]; rows 1,3: b[row-1] + b[row]
+}
+__device__ __forceinline__ float row_sum(float v) {      // sum over the 16 lanes of a row, in every lane
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return v;
+}
+
 template <int C, int MASK>
-__global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const float* __restrict__ G0p,
+__device__ __forceinline__ void backward_queue(const float* s, const Gsym<float, 2, C, MASK>& G, WaveLdsBwd& lds,
+                                               int n, int lane, float* __restrict__ gacc, uint32_t N) {
+    using BL = BwdLayout<2, C>;
+    constexpr int NV = BL::N;
+    if (n == 0) return;
+    if (lane < 8) {           // neutral records behind the last one (their sums are never flushed)
+        lds.t.queue[n + lane][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lds.t.queue[n + lane][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int row = lane >> 4, col = lane & 15;
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        float part[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const Rec r = make_rec(lds.t.queue[k0 + u][0], lds.t.queue[k0 + u][1]);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) part[u][k] = 0.f;
+            bwd_accumulate<float, 2, C, MASK>(part[u], s, r.mu, r.con, r.v, G);
+        }
+        // lanes 0-31 <- records u, lanes 32-63 <- u+4 ; then rows {0,2} <- u, rows {1,3} <- u+2
+        float y0[NV], y1[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const float x0 = swap32_add(part[0][k], part[4][k]);
+            const float x1 = swap32_add(part[1][k], part[5][k]);
+            const float x2 = swap32_add(part[2][k], part[6][k]);
+            const float x3 = swap32_add(part[3][k], part[7][k]);
+            y0[k] = row_sum(swap16_add(x0, x2));     // row r holds record 2r
+            y1[k] = row_sum(swap16_add(x1, x3));     // row r holds record 2r + 1
+        }
+        if (col == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                lds.sums[k0 + 2 * row][k] = y0[k];
+                lds.sums[k0 + 2 * row + 1][k] = y1[k];
+            }
+        }
+    }
+    for (int q0 = 0; q0 < n; q0 += 64) {
+        const int slot = q0 + lane;
+        if (slot < n) {
+            const uint32_t j = lds.qj[slot];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) atomicAdd(&gacc[(size_t)k * N + j], lds.sums[slot][k]);
+        }
+    }
+}
+
+template <int C, int MASK>
+__global__ __launch_bounds__(256, PIGS_BWD_WAVES) void binned_backward_kernel(PlanView pv, const float* __restrict__ G0p,
                                                               const float* __restrict__ G1p,
                                                               const float* __restrict__ G2p,
                                                               const float* __restrict__ G3p) {
-    using BL = BwdLayout<2, C>;
+    __shared__ WaveLdsBwd lds_all[4];
     const int lane = threadIdx.x & 63;
-    const uint32_t cell = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t cell = blockIdx.x * 4 + (uint32_t)wave;
     const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
     const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
     if (sbeg >= send) return;
+    WaveLdsBwd& lds = lds_all[wave];
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
     const float INF = __builtin_huge_valf();
 
     for (uint32_t base = sbeg; base < send; base += 64) {
-        const uint32_t i = base + lane;
-        const bool valid = i < send;
-        uint32_t m = 0u;
-        float s[2] = {0.f, 0.f};
-        if (valid) {
-            const SPoint sp = pv.spts[i];
-            s[0] = sp.x; s[1] = sp.y; m = sp.m;
-        }
-        const float bx0 = wave_min_bcast(valid ? s[0] : INF), bx1 = wave_max_bcast(valid ? s[0] : -INF);
-        const float by0 = wave_min_bcast(valid ? s[1] : INF), by1 = wave_max_bcast(valid ? s[1] : -INF);
+        const bool valid = base + lane < send;
+        SPoint sp = {0.f, 0.f, 0u};
+        if (valid) sp = pv.spts[base + lane];
+        float s[2] = {sp.x, sp.y};
+        const float bx0 = wave_min_dpp(valid ? s[0] : INF), bx1 = wave_max_dpp(valid ? s[0] : -INF);
+        const float by0 = wave_min_dpp(valid ? s[1] : INF), by1 = wave_max_dpp(valid ? s[1] : -INF);
         if (!valid) { s[0] = bx0; s[1] = by0; }
 
         Gsym<float, 2, C, MASK> G;
-        G.load((int64_t)m, G0p, G1p, G2p, G3p);
+        G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
         if (!valid) {   // lanes without a point contribute nothing
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
@@ -688,32 +768,23 @@ __global__ __launch_bounds__(256) void binned_backward_kernel(PlanView pv, const
                 G.g3[0][ch] = G.g3[1][ch] = G.g3[2][ch] = G.g3[3][ch] = 0.f;
             }
         }
-
-        for_each_candidate_step(pv, gg, level_mask, bx0, by0, bx1, by1, lane,
-                                [&](uint32_t j0, const float4, const float4, uint64_t mask) {
-            float mine[BL::N];
-#pragma unroll
-            for (int k = 0; k < BL::N; ++k) mine[k] = 0.f;
-            uint64_t rest = mask;
-            while (rest) {
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                const Rec r = load_rec(pv.rec, j0 + (uint32_t)b);
-                float part[BL::N];
-#pragma unroll
-                for (int k = 0; k < BL::N; ++k) part[k] = 0.f;
-                bwd_accumulate<float, 2, C, MASK>(part, s, r.mu, r.con, r.v, G);
-#pragma unroll
-                for (int k = 0; k < BL::N; ++k) {
-                    const float tot = wave_sum_bcast(part[k]);
-                    mine[k] = (lane == b) ? tot : mine[k];
-                }
+        int qn = 0;
+        traverse(pv, gg, level_mask, bx0, by0, bx1, by1, lane, lds.t,
+                 [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
+            const int cnt = __builtin_popcountll(mask);
+            if (qn + cnt > QCAP) {
+                backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
+                qn = 0;
             }
+            const int slot = qn + lanes_below(mask);
             if (mask >> lane & 1ull) {
-#pragma unroll
-                for (int k = 0; k < BL::N; ++k) atomicAdd(&pv.gacc[(size_t)k * pv.N + j0 + lane], mine[k]);
+                lds.t.queue[slot][0] = A;
+                lds.t.queue[slot][1] = B;
+                lds.qj[slot] = j;
             }
+            qn += cnt;
         });
+        backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
     }
 }
 
