@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         a.params->gg = g;
         a.params->sg = sg;
     }
-    if (blockIdx.x * 256 < a.N) {       // block-uniform: whole waves enter
+    // Gaussian workgroups first, sample workgroups after them: the two halves are independent
+    // latency chains (load -> returning atomic -> store) and run concurrently on different CUs
+    const uint32_t gblocks = (a.N + 255) / 256;
+    if (blockIdx.x < gblocks) {         // block-uniform: whole waves enter
         const uint32_t i = blockIdx.x * 256 + threadIdx.x;
         const bool valid = i < a.N;
         uint32_t key = 0xffffffffu;
@@ -242,10 +245,9 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) lv |= __shfl_xor(lv, o);
         if (lane == 0 && (lv & ~*(volatile uint32_t*)&a.scratch->level_mask)) atomicOr(&a.scratch->level_mask, lv);
-    }
-    if (blockIdx.x * 1024 < a.M) {
+    } else {
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
-        const uint32_t i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + lane;
+        const uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
         uint32_t id[4], base[4];
         Run r[4];
 #pragma unroll
@@ -321,13 +323,15 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
 // Launch 4: scatter into sorted order (no atomics: position = cell start + rank), publish the
 // level mask and hand the scratch back zeroed.
 __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) {
+    const uint32_t gblocks = (a.N + 255) / 256;
+    const bool gpart = blockIdx.x < gblocks;
+    const uint32_t i = (gpart ? blockIdx.x : blockIdx.x - gblocks) * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.params->level_mask = a.scratch->level_mask;
         uint32_t* z = (uint32_t*)a.scratch;
         for (uint32_t k = 0; k < sizeof(PlanScratch) / 4; ++k) z[k] = 0;
     }
-    if (i < a.N) {
+    if (gpart && i < a.N) {
         const uint2 kr = a.gkey[i];
         const uint32_t pos = a.starts[kr.x] + kr.y;
         float v[3] = {0.f, 0.f, 0.f};
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 2], v[0], v[1], v[2]);
         a.g2o[pos] = i;
     }
-    if (i < a.M) {
+    if (!gpart && i < a.M) {
         const uint2 kr = a.skey[i];
         const float2 p = ((const float2*)a.samples)[i];
         SPoint sp;
@@ -874,9 +878,9 @@ int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, i
     const uint32_t nmax = (uint32_t)(N > M ? N : M);
     hipLaunchKernelGGL(plan_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
     const uint32_t gb = (uint32_t)((N + 255) / 256), sb = (uint32_t)((M + 1023) / 1024);
-    hipLaunchKernelGGL(plan_count_kernel, dim3(gb > sb ? gb : sb), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(gb + sb), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(p.scan_blocks), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(plan_scatter_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (uint32_t)((M + 255) / 256)), dim3(256), 0, stream, a);
     return launch_status();
 }
 
