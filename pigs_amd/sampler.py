@@ -246,6 +246,7 @@ class GaussianSampler:
                         samples.detach().contiguous())
         self._cache = {}
         self._plan = None
+        self._neighbors = None
         mc, vc, cc, sc = self._inputs
         use_plan = self.backend == "binned" or (
             self.backend == "auto" and N * sc.shape[0] >= self.BINNED_AUTO_MIN_PAIRS)
@@ -314,3 +315,21 @@ class GaussianSampler:
     def sample_gaussians_third_derivative(self):
         """third derivatives [M, d, d, d, c]"""
         return self._get(3)
+
+    # ------------------------------------------------------------------ neighbour aggregation
+    def preprocess_aggregate(self):
+        """Build the Gaussian <-> Gaussian neighbour structure for :meth:`aggregate_neighbors`
+        (model_pn.py:257).  Semantics are this repo's own (parity unpinned): pigs_amd/aggregate.py."""
+        from . import aggregate
+        means, _, conics, _ = self._require_inputs()
+        self._neighbors = aggregate.neighbor_structure(means.detach(), conics.detach(), self.q_max)
+
+    def aggregate_neighbors(self, features, transform, queries, keys, frequencies, distance_transform):
+        """[N, L] attention-weighted neighbour messages (model_pn.py:262-264); differentiable wrt all
+        six arguments (test_neighbor_aggregation.py:89-98).  Parity unpinned: pigs_amd/aggregate.py."""
+        from . import aggregate
+        if getattr(self, "_neighbors", None) is None:
+            raise RuntimeError("preprocess_aggregate() must be called before aggregate_neighbors()")
+        mask, delta, g = self._neighbors
+        return aggregate.aggregate(mask, delta.to(features.dtype), g.to(features.dtype), features, transform,
+                                   queries, keys, frequencies, distance_transform)
