@@ -190,16 +190,33 @@ def main():
             loss = ((u[:, 0] - (uxx[:, 0, 0, 0] + uxx[:, 1, 1, 0])) ** 2).mean() + (ux ** 2).mean()
             return torch.autograd.grad(loss, list(req.values()))
 
-        nb = max(1, min(a.steps, 3 if a.workload == "c3" else 10))
-        train_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(nb):
-            train_step()
-        barrier()
-        fwd_bwd = {"ms_per_step": (time.perf_counter() - t0) / nb * 1e3, "steps": nb,
-                   "what": "preprocess + fused fwd(0..2) + residual loss + fused bwd"
-                           + (" + all-reduce of [N,6] grads" if dist is not None else "")}
+        gouts = None
+
+        def sampler_step():
+            # the sampler's own share of a training step: incoming gradients supplied, no loss kernels
+            nonlocal gouts
+            m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
+            sampler.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
+            outs = sampler.sample((0, 1, 2))
+            if gouts is None:
+                gouts = tuple(torch.randn_like(o) for o in outs)
+            return torch.autograd.grad(outs, list(req.values()), grad_outputs=gouts)
+
+        def timed(fn, n):
+            fn()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            return (time.perf_counter() - t0) / n * 1e3
+
+        nb = max(1, min(a.steps, 10))
+        fwd_bwd = {"ms_per_step": timed(train_step, nb), "sampler_only_ms_per_step": timed(sampler_step, nb),
+                   "steps": nb,
+                   "what": "ms_per_step: preprocess + fused fwd(0..2) + torch residual loss + fused bwd; "
+                           "sampler_only: the same without the loss (grad_outputs supplied)"
+                           + ("; parameter grads all-reduced as one [N,6] buffer" if dist is not None else "")}
 
     line = {
         "metric": "sample-points/sec (fwd + 1st + 2nd derivatives, fused)", "value": value,

@@ -205,6 +205,26 @@ __device__ __forceinline__ Run run_of(uint32_t k, int lane) {
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     __shared__ float shb[4][8];
     const int lane = threadIdx.x & 63;
+    // Every dependent memory round trip costs 2-4 us in this kernel (in-kernel stamps): issue the
+    // workgroup's own loads first, so they fly while the bounding-box partials are reduced.
+    const uint32_t gblocks = (a.N + 255) / 256;
+    const bool gpart = blockIdx.x < gblocks;
+    float gm[2] = {0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f};
+    float2 pt[4];
+    const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
+    if (gpart) {
+        if (gi < a.N) {
+            gm[0] = a.means[2 * gi]; gm[1] = a.means[2 * gi + 1];
+            gc[0] = a.conics[3 * gi]; gc[1] = a.conics[3 * gi + 1]; gc[2] = a.conics[3 * gi + 2];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            pt[k] = i < a.M ? ((const float2*)a.samples)[i] : make_float2(0.f, 0.f);
+        }
+    }
     float gbox[4], sbox[4];
     reduce_boxes(a.boxes, gbox, sbox, shb);
     const GaussGrid g = gauss_grid(gbox, a.G0);
@@ -215,15 +235,14 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     }
     // Gaussian workgroups first, sample workgroups after them: the two halves are independent
     // latency chains (load -> returning atomic -> store) and run concurrently on different CUs
-    const uint32_t gblocks = (a.N + 255) / 256;
-    if (blockIdx.x < gblocks) {         // block-uniform: whole waves enter
-        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (gpart) {                        // block-uniform: whole waves enter
+        const uint32_t i = gi;
         const bool valid = i < a.N;
         uint32_t key = 0xffffffffu;
         int l = 0;
         if (valid) {
-            const float mx = a.means[2 * i], my = a.means[2 * i + 1];
-            const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
+            const float mx = gm[0], my = gm[1];
+            const float ca = gc[0], cb = gc[1], cc = gc[2];
             // half extents of the q <= q_max ellipse: sqrt(q_max * Sigma_xx), Sigma = C^-1
             const float det = ca * cc - cb * cb;
             const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
@@ -247,7 +266,6 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         if (lane == 0 && (lv & ~*(volatile uint32_t*)&a.scratch->level_mask)) atomicOr(&a.scratch->level_mask, lv);
     } else {
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
-        const uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
         uint32_t id[4], base[4];
         Run r[4];
 #pragma unroll
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             const uint32_t i = i0 + 64 * k;
             id[k] = 0xffffffffu;
             if (i < a.M) {
-                const float2 p = ((const float2*)a.samples)[i];
+                const float2 p = pt[k];
                 const int cx = (int)clampf((p.x - sg.ox) * sg.inv_w, 0.f, (float)(sg.nx - 1));
                 const int cy = (int)clampf((p.y - sg.oy) * sg.inv_w, 0.f, (float)(sg.ny - 1));
                 id[k] = sample_cell_id(cx, cy, sg.nx);
@@ -875,7 +893,6 @@ int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, i
     a.q_max = q_max;
 
     clear_hip_error();
-    const uint32_t nmax = (uint32_t)(N > M ? N : M);
     hipLaunchKernelGGL(plan_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
     const uint32_t gb = (uint32_t)((N + 255) / 256), sb = (uint32_t)((M + 1023) / 1024);
     hipLaunchKernelGGL(plan_count_kernel, dim3(gb + sb), dim3(256), 0, stream, a);
