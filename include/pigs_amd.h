@@ -53,6 +53,8 @@ enum pigs_dtype { PIGS_F32 = 0, PIGS_F64 = 1 };
 
 int pigs_abi_version(void);
 const char* pigs_status_string(int status);
+/* text of the HIP error behind the calling thread's last PIGS_ERR_LAUNCH */
+const char* pigs_last_hip_error(void);
 
 /* Dense forward: out_k = sum over ALL N Gaussians (exact reference semantics, no culling). */
 int pigs_sample_forward(int dtype, int d, int c, int orders_mask, int64_t N, int64_t M,

@@ -5,6 +5,11 @@ There is no fallback: if the HIP library is missing or a call fails, an exceptio
 import ctypes
 import os
 
+# torch must be imported before libpigs_amd.so is loaded: both need libamdhip64, and the library
+# must bind to the HIP runtime instance PyTorch brings along (loaded the other way round, the
+# process holds two runtimes and ours reports "no ROCm-capable device").
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 # PIGS_AMD_LIB selects another build of the same ABI (kernel experiments); default: in-tree library
 LIB_PATH = os.environ.get("PIGS_AMD_LIB") or os.path.join(HERE, "libpigs_amd.so")
@@ -20,6 +25,7 @@ _i64 = ctypes.c_int64
 SIGNATURES = {
     "pigs_abi_version": (_i, []),
     "pigs_status_string": (ctypes.c_char_p, [_i]),
+    "pigs_last_hip_error": (ctypes.c_char_p, []),
     "pigs_sample_forward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp]),
     "pigs_sample_backward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp] * 3 + [_vp]),
     "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
@@ -59,5 +65,8 @@ def load():
 
 def check(status, what):
     if status != 0:
-        msg = load().pigs_status_string(status).decode()
+        lib = load()
+        msg = lib.pigs_status_string(status).decode()
+        if status == 3:
+            msg += ": " + lib.pigs_last_hip_error().decode()
         raise PigsError(f"{what}: {msg} (status {status})")

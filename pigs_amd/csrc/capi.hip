@@ -3,6 +3,10 @@
 
 using namespace pigs;
 
+namespace pigs {
+thread_local hipError_t g_last_hip_error = hipSuccess;
+}
+
 static int check_common(int dtype, int d, int c, int mask, int64_t N, int64_t M, const void* means,
                         const void* conics, const void* values, const void* samples) {
     if (dtype != PIGS_F32 && dtype != PIGS_F64) return PIGS_ERR_UNSUPPORTED;
@@ -16,6 +20,8 @@ static int check_common(int dtype, int d, int c, int mask, int64_t N, int64_t M,
 extern "C" {
 
 int pigs_abi_version(void) { return PIGS_ABI_VERSION; }
+
+const char* pigs_last_hip_error(void) { return hipGetErrorString(g_last_hip_error); }
 
 const char* pigs_status_string(int status) {
     switch (status) {

@@ -31,7 +31,13 @@ int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float 
 
 // The HIP "last error" is sticky per thread and the host process (PyTorch) makes its own HIP
 // calls: clear it before a launch, read it after.
+extern thread_local hipError_t g_last_hip_error;      // capi.hip; reported by pigs_last_hip_error()
 inline void clear_hip_error() { (void)hipGetLastError(); }
-inline int launch_status() { return hipGetLastError() == hipSuccess ? PIGS_OK : PIGS_ERR_LAUNCH; }
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return PIGS_OK;
+    g_last_hip_error = e;
+    return PIGS_ERR_LAUNCH;
+}
 
 }  // namespace pigs

@@ -42,6 +42,25 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _on_device:
+    """``torch.cuda.device(dev)`` only when ``dev`` is not already current (the context manager
+    costs microseconds, which matters for the launch-bound problem sizes of the PINN loops)."""
+
+    def __init__(self, device):
+        self.ctx = None if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
+_WORKSPACE_BYTES = {}
+
+
 def _mask_orders(mask):
     return [k for k in range(4) if mask >> k & 1]
 
@@ -56,11 +75,14 @@ class Plan:
     def __init__(self, means, values, conics, samples, q_max, scratch):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
-        nbytes = lib.pigs_plan_workspace_bytes(self.N, self.M, self.c)
+        key = (self.N, self.M, self.c)
+        nbytes = _WORKSPACE_BYTES.get(key)
+        if nbytes is None:
+            nbytes = _WORKSPACE_BYTES[key] = lib.pigs_plan_workspace_bytes(self.N, self.M, self.c)
         if nbytes == 0:
             raise _lib.PigsError(f"binned path does not support N={self.N} M={self.M} c={self.c}")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
-        with torch.cuda.device(means.device):
+        with _on_device(means.device):
             rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, _ptr(scratch), self.N, self.M, self.c, self.q_max,
                                      _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
                                      _stream(means.device))
@@ -83,7 +105,7 @@ def forward_raw(means, values, conics, samples, mask, plan=None):
     for k in _mask_orders(mask):
         outs[k] = torch.empty(_out_shape(k, M, d, c), dtype=means.dtype, device=means.device)
     if M > 0:
-        with torch.cuda.device(means.device):
+        with _on_device(means.device):
             if plan is not None:
                 rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
                                            _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]),
@@ -108,7 +130,7 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
     g_values = torch.empty_like(values)
     g_conics = torch.empty_like(conics)
     if N > 0:
-        with torch.cuda.device(means.device):
+        with _on_device(means.device):
             if plan is not None and M > 0:
                 rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
                                             _ptr(gouts[0]), _ptr(gouts[1]), _ptr(gouts[2]),
