@@ -26,7 +26,10 @@
 #define PIGS_FWD_UNROLL 2     // accepted records evaluated per loop iteration
 #endif
 #ifndef PIGS_BWD_WAVES
-#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to
+#define PIGS_BWD_WAVES 3      // waves per SIMD the backward kernel's register budget is held to
+#endif
+#ifndef PIGS_TRAV_STEPS
+#define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
 #endif
 #ifndef PIGS_FWD_CELL_RECT
 #define PIGS_FWD_CELL_RECT 0  // forward: cull against the cell rectangle (1) or the points' tight box (0)
@@ -102,6 +105,7 @@ struct BuildArgs {
     uint2* gkey;          // per Gaussian {cell key, rank inside the cell}
     uint2* skey;          // per point    {cell id,  rank inside the cell}
     float4* rec;
+    float4* gbox;
     uint32_t* g2o;
     SPoint* spts;
     const float* means;
@@ -359,6 +363,14 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
         a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
         a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 2], v[0], v[1], v[2]);
+        {   // bounding box of the q <= q_max ellipse: half extents sqrt(q_max Sigma_xx), sqrt(q_max Sigma_yy)
+            const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
+            const float k = a.q_max / (ca * cc - cb * cb);
+            float hx = sqrtf(k * cc), hy = sqrtf(k * ca);
+            if (!(hx < 3.0e38f)) hx = 3.0e38f;      // NaN / inf (degenerate conic): always a candidate
+            if (!(hy < 3.0e38f)) hy = 3.0e38f;
+            a.gbox[pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], hx * 1.0001f, hy * 1.0001f);
+        }
         a.g2o[pos] = i;
     }
     if (!gpart && i < a.M) {
@@ -474,10 +486,13 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mas
 // ------------------------------------------------------------------------------------------
 constexpr int QCAP = 128;   // accepted records queued per wave before an evaluation run
 
+constexpr int CCAP = 256;   // bbox-accepted candidate indices buffered per wave before the exact test
+
 struct WaveLds {
     float4 queue[QCAP + 8][2];
     uint32_t row_a0[64];
     uint32_t row_a1[64];
+    uint32_t cand[CCAP + 64];
 };
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -563,7 +578,12 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
             jbv = pv.starts[lds.row_a0[lane]];
             lenv = pv.starts[lds.row_a1[lane]] - jbv;
         }
-        // 4. wave-uniform walk over the rows' ranges, one step (64 candidates) ahead
+        // 4. two-stage culling.  Stage 1: the rows' ranges are walked in wave-uniform order, PIGS_TRAV_STEPS
+        //    steps (64 candidates each) at a time -- their 16-byte {centre, half extents} records
+        //    are all in flight together (every dependent round trip costs microseconds here) --
+        //    and tested box against box (8 instructions); survivors' indices go to an LDS list.
+        //    Stage 2: survivors' full records are gathered 64 at a time, tested exactly (ellipse
+        //    against box) and handed to `batch`.
         int r = -1;
         uint32_t j0 = 0, je = 0;
         auto advance = [&]() -> bool {
@@ -575,34 +595,59 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
             }
             return true;
         };
-        bool have = advance();
-        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
-        uint32_t j = 0;
-        bool in = false;
-        if (have) {
-            j = j0 + lane;
-            in = j < je;
-            if (!in) j = j0;
-            A = pv.rec[2 * j];
-            B = pv.rec[2 * j + 1];
-        }
-        while (have) {
-            have = advance();
-            float4 An = A, Bn = B;
-            uint32_t jn = 0;
-            bool inn = false;
-            if (have) {
-                jn = j0 + lane;
-                inn = jn < je;
-                if (!inn) jn = j0;
-                An = pv.rec[2 * jn];
-                Bn = pv.rec[2 * jn + 1];
+        int cn = 0;
+        auto exact_stage = [&]() {
+            for (int b0 = 0; b0 < cn; b0 += 128) {
+                // two gathers in flight
+                const bool in0 = b0 + lane < cn, in1 = b0 + 64 + lane < cn;
+                const uint32_t i0 = in0 ? lds.cand[b0 + lane] : lds.cand[0];
+                const uint32_t i1 = in1 ? lds.cand[b0 + 64 + lane] : lds.cand[0];
+                const float4 A0 = pv.rec[2 * i0], B0 = pv.rec[2 * i0 + 1];
+                float4 A1 = A0, B1 = B0;
+                if (b0 + 64 < cn) { A1 = pv.rec[2 * i1]; B1 = pv.rec[2 * i1 + 1]; }
+                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.x, bx0, by0, bx1, by1, pv.q_max));
+                if (m0) batch(A0, B0, m0, i0);
+                if (b0 + 64 < cn) {
+                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.x, bx0, by0, bx1, by1, pv.q_max));
+                    if (m1) batch(A1, B1, m1, i1);
+                }
             }
-            const bool ok = in && ellipse_reaches_rect(A, B.x, bx0, by0, bx1, by1, pv.q_max);
-            const uint64_t mask = __ballot(ok);
-            if (mask) batch(A, B, mask, j);
-            A = An; B = Bn; j = jn; in = inn;
+            cn = 0;
+        };
+        bool have = advance();
+        while (have) {
+            uint32_t sj[PIGS_TRAV_STEPS], se[PIGS_TRAV_STEPS];
+            float4 T[PIGS_TRAV_STEPS];
+            int ns = 0;
+#pragma unroll
+            for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
+                sj[u] = j0; se[u] = je;
+                if (have) {
+                    ns = u + 1;
+                    const uint32_t j = j0 + lane < je ? j0 + lane : j0;
+                    T[u] = pv.gbox[j];
+                    have = advance();
+                } else {
+                    se[u] = sj[u];          // empty step
+                    T[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
+                if (u < ns) {
+                    const float ex = fmaxf(fmaxf(bx0 - T[u].x, T[u].x - bx1), 0.f);
+                    const float ey = fmaxf(fmaxf(by0 - T[u].y, T[u].y - by1), 0.f);
+                    const bool ok = (sj[u] + lane < se[u]) && ex <= T[u].z && ey <= T[u].w;
+                    const uint64_t mask = __ballot(ok);
+                    if (mask) {
+                        if (ok) lds.cand[cn + lanes_below(mask)] = sj[u] + lane;
+                        cn += __builtin_popcountll(mask);
+                        if (cn > CCAP - 64) exact_stage();
+                    }
+                }
+            }
         }
+        exact_stage();
     }
 }
 
@@ -851,6 +896,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     v.params = (const PlanParams*)(b + p.off_params);
     v.starts = (const uint32_t*)(b + p.off_starts);
     v.rec = (const float4*)(b + p.off_rec);
+    v.gbox = (const float4*)(b + p.off_box);
     v.g2o = (const uint32_t*)(b + p.off_g2o);
     v.spts = (const SPoint*)(b + p.off_spts);
     v.N = (uint32_t)p.N; v.M = (uint32_t)p.M;
@@ -898,6 +944,7 @@ int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, i
     a.gkey = (uint2*)(b + p.off_gkey);
     a.skey = (uint2*)(b + p.off_skey);
     a.rec = (float4*)(b + p.off_rec);
+    a.gbox = (float4*)(b + p.off_box);
     a.g2o = (uint32_t*)(b + p.off_g2o);
     a.spts = (SPoint*)(b + p.off_spts);
     a.means = (const float*)means; a.conics = (const float*)conics;

@@ -85,7 +85,7 @@ struct PlanLayout {
     uint32_t ncounts;          // sbase + scells_cap
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     uint32_t scan_blocks;      // workgroups of the scan = ceil((ncounts + 1) / PLAN_SCAN_BLOCK)
-    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_gkey, off_skey, off_rec, off_g2o, off_spts, off_gacc,
+    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_gkey, off_skey, off_rec, off_box, off_g2o, off_spts, off_gacc,
         total_bytes;
 };
 
@@ -126,6 +126,7 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_gkey = o;     o = align_up(o + sizeof(uint2) * (size_t)N, 256);      // {cell key, rank in cell}
     p.off_skey = o;     o = align_up(o + sizeof(uint2) * (size_t)M, 256);
     p.off_rec = o;      o = align_up(o + 32 * (size_t)N, 256);
+    p.off_box = o;      o = align_up(o + 16 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
     p.off_spts = o;     o = align_up(o + sizeof(SPoint) * (size_t)M, 256);
     p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [8][N]
@@ -139,6 +140,7 @@ struct PlanView {
     const uint32_t* starts;       // [ncounts + 1] exclusive scan of the cell counters: Gaussian cells at
                                   // [0, gcells), sample cells at [sbase, sbase + scells_cap)
     const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {c, v0, v1, v2}  (c <= 3)
+    const float4* gbox;           // [N] sorted: {mux, muy, hx, hy} = centre and half extents of the q <= q_max ellipse
     const uint32_t* g2o;          // sorted Gaussian -> original index
     const SPoint* spts;           // sorted points: coordinates + original index
     uint32_t N, M;

@@ -41,11 +41,12 @@ class _Replicated(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1):
+            return (None, *grads)          # single process: nothing to sum, no packing copy either
         shapes = [g.shape for g in grads]
         n = shapes[0][0]
         packed = torch.cat([g.reshape(n, -1) for g in grads], dim=1).contiguous()
-        if dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
         out, col = [], 0
         for shp in shapes:
             w = 1
