@@ -26,7 +26,10 @@
 #define PIGS_FWD_UNROLL 2     // accepted records evaluated per loop iteration
 #endif
 #ifndef PIGS_BWD_WAVES
-#define PIGS_BWD_WAVES 3      // waves per SIMD the backward kernel's register budget is held to
+#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to
+#endif
+#ifndef PIGS_BWD_GROUP
+#define PIGS_BWD_GROUP 4      // records reduced together by the backward's butterfly (4 or 8)
 #endif
 #ifndef PIGS_TRAV_STEPS
 #define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
@@ -488,12 +491,15 @@ constexpr int QCAP = 128;   // accepted records queued per wave before an evalua
 
 constexpr int CCAP = 256;   // bbox-accepted candidate indices buffered per wave before the exact test
 
-struct WaveLds {
-    float4 queue[QCAP + 8][2];
+template <int Q>
+struct WaveLdsT {
+    static constexpr int CAP = Q;
+    float4 queue[Q + 8][2];
     uint32_t row_a0[64];
     uint32_t row_a1[64];
     uint32_t cand[CCAP + 64];
 };
+using WaveLds = WaveLdsT<QCAP>;
 
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_keep_f32(float v) {     // lanes without a source keep v
@@ -538,9 +544,9 @@ __device__ __forceinline__ void evaluate_queue(float* acc, const float* s, float
 
 // Steps 3-4 for one pass.  `batch(A, B, mask, j)` is called for every step with accepted
 // candidates (A, B: this lane's record; j: its sorted Gaussian index).
-template <typename Batch>
+template <typename Lds, typename Batch>
 __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask, float bx0,
-                                         float by0, float bx1, float by1, int lane, WaveLds& lds, Batch&& batch) {
+                                         float by0, float bx1, float by1, int lane, Lds& lds, Batch&& batch) {
     // 3. lane = level: rectangle of cells within one cell of the box; rows scanned over lanes
     const bool occ = lane < pv.L && (level_mask >> lane & 1u);
     const int sh = lane < pv.L ? lane : 0;
@@ -740,10 +746,11 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void bin
 // per lane and value into gacc[k][j] (queue order follows the sorted order, so consecutive lanes
 // hit near-consecutive addresses); plan_unpermute_kernel writes the caller's layout.
 // ------------------------------------------------------------------------------------------
+constexpr int QCAP_BWD = 64;      // smaller queue than the forward's: LDS, not registers, caps the occupancy here
 struct WaveLdsBwd {
-    WaveLds t;                    // queue + row tables (shared code with the forward)
-    uint32_t qj[QCAP + 8];        // sorted Gaussian index of every queue slot
-    float sums[QCAP + 8][8];      // per-slot reduced contributions
+    WaveLdsT<QCAP_BWD> t;         // queue + row tables (shared code with the forward)
+    uint32_t qj[QCAP_BWD + 8];    // sorted Gaussian index of every queue slot
+    float sums[QCAP_BWD + 8][8];  // per-slot reduced contributions
 };
 
 // hipcc (ROCm 7.2) mis-lowers __builtin_amdgcn_permlane{32,16}_swap when both results feed one
@@ -776,6 +783,7 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
         lds.t.queue[n + lane][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int row = lane >> 4, col = lane & 15;
+#if PIGS_BWD_GROUP == 8
     for (int k0 = 0; k0 < n; k0 += 8) {
         float part[8][NV];
 #pragma unroll
@@ -804,6 +812,32 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
             }
         }
     }
+#else
+    // four records per round: the same 2.5 NV instructions per record as eight, half the registers
+    for (int k0 = 0; k0 < n; k0 += 4) {
+        float part[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const Rec r = make_rec(lds.t.queue[k0 + u][0], lds.t.queue[k0 + u][1]);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) part[u][k] = 0.f;
+            bwd_accumulate<float, 2, C, MASK>(part[u], s, r.mu, r.con, r.v, G);
+        }
+        // lanes 0-31 <- records 0 / 1, lanes 32-63 <- 2 / 3 ; then rows {0,2} <- even, rows {1,3} <- odd:
+        // row 0 = record 0, row 1 = record 1, row 2 = record 2, row 3 = record 3
+        float y[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const float x0 = swap32_add(part[0][k], part[2][k]);
+            const float x1 = swap32_add(part[1][k], part[3][k]);
+            y[k] = row_sum(swap16_add(x0, x1));
+        }
+        if (col == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) lds.sums[k0 + row][k] = y[k];
+        }
+    }
+#endif
     for (int q0 = 0; q0 < n; q0 += 64) {
         const int slot = q0 + lane;
         if (slot < n) {
@@ -855,7 +889,7 @@ __global__ __launch_bounds__(256, PIGS_BWD_WAVES) void binned_backward_kernel(Pl
         traverse(pv, gg, level_mask, bx0, by0, bx1, by1, lane, lds.t,
                  [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
             const int cnt = __builtin_popcountll(mask);
-            if (qn + cnt > QCAP) {
+            if (qn + cnt > QCAP_BWD) {
                 backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
                 qn = 0;
             }
