@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bwd", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "dense", "binned"])
+    # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo, ranks share devices)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     return ap.parse_args()
 
 
@@ -100,16 +102,23 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     import pigs_amd
-    pigs_amd.build()
+    if local_rank == 0:
+        pigs_amd.build()                 # no-op when the in-tree library matches the sources
+    if dist is not None:
+        dist.barrier()                   # the other ranks wait for the library instead of rebuilding it
     from diff_gaussian_sampling import GaussianSampler
     from pigs_amd import synthetic, sampler as S
 

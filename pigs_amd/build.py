@@ -6,6 +6,7 @@ hipcc cross-compiles without a GPU, so this also runs in GPU-less containers.  T
 built in-tree (git-ignored) so that it travels with the source tree to the GPU box.
 """
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -27,11 +28,23 @@ def _deps():
         os.path.join(HERE, "..", "include", "pigs_amd.h")]
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """Hash of every source the library is built from plus the flags (content, not mtimes: the
+    tree is copied between machines and copies do not keep timestamps)."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in _deps():
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    return open(STAMP).read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -39,7 +52,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
-    tmp = LIB + ".tmp"
+    tmp = f"{LIB}.{os.getpid()}.tmp"      # several ranks may build at once: no shared temp file
     cmd = [hipcc] + FLAGS + ["-o", tmp] + sources()
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -49,6 +62,9 @@ def build(force=False, verbose=False):
     if verbose and proc.stdout.strip():
         print(proc.stdout)
     os.replace(tmp, LIB)
+    with open(f"{STAMP}.{os.getpid()}.tmp", "w") as f:
+        f.write(source_hash())
+    os.replace(f"{STAMP}.{os.getpid()}.tmp", STAMP)
     return LIB
 
 
