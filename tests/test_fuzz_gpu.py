@@ -1,0 +1,73 @@
+"""GPU fuzz: the binned path against the dense HIP path (itself pinned to the oracle) on random
+problem shapes -- sizes, scales over several orders of magnitude, strong anisotropy, clustered
+and duplicated points, Gaussians far outside the sampled region."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Sampler(hip_lib):
+    assert torch.cuda.is_available()
+    from diff_gaussian_sampling import GaussianSampler
+    return GaussianSampler
+
+
+def make_case(rng):
+    N = int(rng.integers(1, 3000))
+    M = int(rng.integers(1, 6000))
+    c = int(rng.integers(1, 4))
+    span = 10.0 ** rng.uniform(-1, 1.5)                       # domain size 0.1 .. 30
+    centre = rng.uniform(-5, 5, 2)
+    means = centre + rng.uniform(-span, span, (N, 2))
+    sig_lo = 10.0 ** rng.uniform(-3, -1) * span
+    sig = sig_lo * 10.0 ** rng.uniform(0, rng.uniform(0.1, 2.5), (N, 2))      # up to 300x spread
+    rho = np.tanh(rng.normal(0, rng.uniform(0.1, 2.0), N))                  # up to |rho| ~ 0.99
+    s0, s1, tau = sig[:, 0] ** 2, sig[:, 1] ** 2, rho * sig[:, 0] * sig[:, 1]
+    det = s0 * s1 - tau ** 2
+    con = np.stack((s1 / det, -tau / det, s0 / det), -1)
+    values = rng.uniform(-1, 1, (N, c))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        pts = centre + rng.uniform(-1.3 * span, 1.3 * span, (M, 2))
+    elif kind == 1:                                             # clusters + duplicates
+        k = max(1, M // 50)
+        cl = centre + rng.uniform(-span, span, (k, 2))
+        pts = cl[rng.integers(0, k, M)] + rng.normal(0, sig_lo * 0.01, (M, 2)) * rng.integers(0, 2, (M, 1))
+    elif kind == 2:                                             # regular grid
+        r = max(1, int(np.sqrt(M)))
+        gx, gy = np.meshgrid(np.linspace(-span, span, r), np.linspace(-span, span, r), indexing="xy")
+        pts = centre + np.stack((gx, gy), -1).reshape(-1, 2)
+    else:                                                       # a thin line
+        t = rng.uniform(-span, span, M)
+        pts = centre + np.stack((t, 0.3 * t + 1e-3 * span), -1)
+    return means, values, con, pts
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_binned_matches_dense(Sampler, seed):
+    rng = np.random.default_rng(1000 + seed)
+    means, values, con, pts = make_case(rng)
+    outs, grads = {}, {}
+    for backend in ("dense", "binned"):
+        t = [torch.tensor(a, dtype=torch.float32, device="cuda") for a in (means, values, con, pts)]
+        for x in t[:3]:
+            x.requires_grad_(True)
+        s = Sampler(True, backend=backend, fuse="all")
+        s.preprocess(t[0], t[1], None, t[2], t[3])
+        o = s.sample((0, 1, 2, 3))
+        torch.manual_seed(seed)
+        loss = sum((x * torch.randn_like(x)).sum() for x in o)
+        loss.backward()
+        outs[backend] = [x.detach() for x in o]
+        grads[backend] = [x.grad for x in t[:3]]
+    for k, (a, b) in enumerate(zip(outs["dense"], outs["binned"])):
+        scale = float(a.abs().max())
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-30, ("order", k, seed)
+    for k, (a, b) in enumerate(zip(grads["dense"], grads["binned"])):
+        scale = float(a.abs().max())
+        # random-sign weights cancel in the gradient sums: fp32 accumulation-order noise only
+        assert float((a - b).abs().max()) <= 5e-5 * scale + 1e-30, ("grad", k, seed)
