@@ -40,14 +40,32 @@ __global__ __launch_bounds__(NW * 64) void dense_forward_kernel(
 #pragma unroll
     for (int k = 0; k < L::N; ++k) acc[k] = T(0);
 
-    for (int64_t n = wave; n < N; n += NW) {
+    // four Gaussians per iteration: their scalar loads are issued together, so one memory round
+    // trip covers four evaluations (a single-record loop waits on every record)
+    constexpr int U = 4;
+    int64_t n = (int64_t)wave * U;
+    for (; n + U <= N; n += (int64_t)NW * U) {
+        T mu[U][D], con[U][NF], v[U][C];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) mu[u][i] = means[(n + u) * D + i];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) con[u][i] = conics[(n + u) * NF + i];
+#pragma unroll
+            for (int i = 0; i < C; ++i) v[u][i] = values[(n + u) * C + i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) fwd_accumulate<T, D, C, MASK>(acc, s, mu[u], con[u], v[u]);
+    }
+    for (int64_t m2 = n; m2 < N && m2 < n + U; ++m2) {          // ragged tail of this wave's last chunk
         T mu[D], con[NF], v[C];
 #pragma unroll
-        for (int i = 0; i < D; ++i) mu[i] = means[n * D + i];
+        for (int i = 0; i < D; ++i) mu[i] = means[m2 * D + i];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) con[i] = conics[n * NF + i];
+        for (int i = 0; i < NF; ++i) con[i] = conics[m2 * NF + i];
 #pragma unroll
-        for (int i = 0; i < C; ++i) v[i] = values[n * C + i];
+        for (int i = 0; i < C; ++i) v[i] = values[m2 * C + i];
         fwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v);
     }
 
@@ -99,13 +117,26 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
     const int64_t per = (M + gridDim.y - 1) / gridDim.y;
     const int64_t m_begin = (int64_t)blockIdx.y * per;
     const int64_t m_end = m_begin + per < M ? m_begin + per : M;
-    for (int64_t m = m_begin + wave; m < m_end; m += NW) {
-        T s[D];
+    // two points per iteration: their scalar loads (coordinates + incoming gradients) are issued
+    // together, halving the exposed memory round trips
+    int64_t m = m_begin + (int64_t)wave * 2;
+    for (; m + 2 <= m_end; m += (int64_t)NW * 2) {
+        T s0[D], s1[D];
 #pragma unroll
-        for (int i = 0; i < D; ++i) s[i] = samples[m * D + i];
-        Gsym<T, D, C, MASK> G;
-        G.load(m, G0, G1, G2, G3);
-        bwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v, G);
+        for (int i = 0; i < D; ++i) { s0[i] = samples[m * D + i]; s1[i] = samples[(m + 1) * D + i]; }
+        Gsym<T, D, C, MASK> Ga, Gb;
+        Ga.load(m, G0, G1, G2, G3);
+        Gb.load(m + 1, G0, G1, G2, G3);
+        bwd_accumulate<T, D, C, MASK>(acc, s0, mu, con, v, Ga);
+        bwd_accumulate<T, D, C, MASK>(acc, s1, mu, con, v, Gb);
+    }
+    if (m < m_end) {                       // odd point of this wave's last pair
+        T s0[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s0[i] = samples[m * D + i];
+        Gsym<T, D, C, MASK> Ga;
+        Ga.load(m, G0, G1, G2, G3);
+        bwd_accumulate<T, D, C, MASK>(acc, s0, mu, con, v, Ga);
     }
 
     if constexpr (NW > 1) {
