@@ -1,14 +1,20 @@
 // Binned (culled) sampler: preprocess (plan build) + forward + backward, float32, d = 2.
 // Data structures and the cut-off rule: plan.h.  Per-pair arithmetic: pair_math.h.
 //
+// Preprocess = 4 launches (bbox partials -> cell key + rank -> scan -> scatter), no memset, no
+// host synchronisation, static memory.
 // Sampling kernels: one wave = one sample cell (<= 64 points per pass, lane = point).  The wave
-// (1) reduces the bounding box of its points, (2) walks, per occupied Gaussian level, the few
-// contiguous record ranges whose cells lie within one cell of that box -- 64 candidates per
-// step, one per lane, coalesced 2 x 16 B loads -- and tests each candidate's q <= q_max ellipse
-// against the box exactly, (3) for every accepted candidate (a bit of the 64-bit ballot) pulls
-// the 32-byte record through the SCALAR data path (wave-uniform address) and evaluates it on
-// all 64 points from SGPR operands.  No LDS, no barriers; HBM traffic is the point stream
-// (perm + coordinates in, outputs out) plus record re-reads that hit L2.
+// reduces the bounding box of its points; forms, lane-parallel, the cell rectangle to visit on
+// every occupied Gaussian level and fetches all the row ranges with one gather; culls the
+// candidates in two stages (16-byte box records, then the exact ellipse-vs-box test on the
+// survivors' full records); compacts the accepted records into a wave-private LDS queue and
+// evaluates them from there with wave-uniform (broadcast) LDS reads.  No workgroup barriers in
+// the sampling kernels; HBM traffic is the point stream (sorted points in, outputs out through
+// the points' original indices) plus record reads that mostly hit L2.
+//
+// Build-time knobs (defaults measured on MI355X): PIGS_FWD_WAVES, PIGS_FWD_UNROLL,
+// PIGS_FWD_BLOCK_WAVES, PIGS_TRAV_STEPS, PIGS_BWD_WAVES, PIGS_BWD_GROUP; PIGS_STAMPS=1 builds the
+// diagnostic variant read by tools/stamps.py.
 #include "pair_math.h"
 #include "plan.h"
 #include "launch.h"
@@ -34,15 +40,6 @@
 #ifndef PIGS_TRAV_STEPS
 #define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
 #endif
-#ifndef PIGS_FWD_CELL_RECT
-#define PIGS_FWD_CELL_RECT 0  // forward: cull against the cell rectangle (1) or the points' tight box (0)
-#endif
-#ifndef PIGS_FWD_TRAVERSE
-#define PIGS_FWD_TRAVERSE 1   // 0: per-level/row loops with their own loads; 1: batched ranges (traverse())
-#endif
-#ifndef PIGS_ABLATE
-#define PIGS_ABLATE 0   // timing-only ablation builds (tools/ablate.sh); 0 in the product
-#endif
 
 
 namespace pigs {
@@ -67,18 +64,6 @@ __device__ __forceinline__ float dpp_f32(float v) {
 }
 // DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
 // row_mirror = 0x140, row_bcast15 = 0x142, row_bcast31 = 0x143.
-__device__ __forceinline__ float wave_sum(float v) {   // result valid in lane 63
-    v += dpp_f32<0xB1>(v);
-    v += dpp_f32<0x4E>(v);
-    v += dpp_f32<0x141>(v);
-    v += dpp_f32<0x140>(v);
-    v += dpp_f32<0x142, 0xA>(v);
-    v += dpp_f32<0x143, 0xC>(v);
-    return v;
-}
-__device__ __forceinline__ float wave_sum_bcast(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum(v)), 63));
-}
 __device__ __forceinline__ float wave_min_bcast(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -87,9 +72,6 @@ __device__ __forceinline__ float wave_min_bcast(float v) {
 __device__ __forceinline__ float wave_max_bcast(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ float uniform_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -408,52 +390,6 @@ __device__ __forceinline__ bool ellipse_reaches_rect(float4 A, float cc, float x
 // wave-uniform) for every Gaussian whose ellipse reaches the box, and `batch_begin(j0)` /
 // `batch_end(j0, mask)` around each step of 64 candidates.
 // ------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------
-// the traversal shared by forward and backward: per occupied level, the contiguous record ranges
-// of the cells within one cell of the box; 64 candidates per step (one per lane), tested
-// exactly; `step(j0, A, B, mask)` receives the step's first sorted index, this lane's record and
-// the ballot of accepted lanes.
-// ------------------------------------------------------------------------------------------
-template <typename Step>
-__device__ __forceinline__ void for_each_candidate_step(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask,
-                                                        float bx0, float by0, float bx1, float by1, int lane,
-                                                        Step&& step) {
-#if PIGS_ABLATE == 3
-    return;
-#endif
-    for (int l = 0; l < pv.L; ++l) {
-        if (!(level_mask >> l & 1u)) continue;
-        const int G = pv.G0 >> l;
-        const float inv_s = gg.inv_s0 * (1.f / (float)(1 << l));
-        const float gmax = (float)(G - 1);
-        // cells within one cell of the box (R <= s_l on this level); the top level has one cell
-        const int cx0 = (int)clampf(floorf((bx0 - gg.ox) * inv_s) - 1.f, 0.f, gmax);
-        const int cx1 = (int)clampf(floorf((bx1 - gg.ox) * inv_s) + 1.f, 0.f, gmax);
-        const int cy0 = (int)clampf(floorf((by0 - gg.oy) * inv_s) - 1.f, 0.f, gmax);
-        const int cy1 = (int)clampf(floorf((by1 - gg.oy) * inv_s) + 1.f, 0.f, gmax);
-        for (int cy = cy0; cy <= cy1; ++cy) {
-            const uint32_t row = pv.level_off[l] + (uint32_t)(cy * G);
-            const uint32_t jb = pv.starts[row + cx0];
-            const uint32_t je = pv.starts[row + cx1 + 1];
-            for (uint32_t j0 = jb; j0 < je; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                bool ok = j < je;
-                const uint32_t jj = ok ? j : jb;
-                const float4 A = pv.rec[2 * jj];
-                const float4 B = pv.rec[2 * jj + 1];
-#if PIGS_ABLATE == 2
-                asm volatile("" ::"v"(A.x), "v"(B.x));
-                ok = false;
-#else
-                ok = ok && ellipse_reaches_rect(A, B.x, bx0, by0, bx1, by1, pv.q_max);
-#endif
-                const uint64_t mask = __ballot(ok);
-                if (mask) step(j0, A, B, mask);
-            }
-        }
-    }
-}
-
 struct Rec {
     float mu[2], con[3], v[3];
 };
@@ -462,10 +398,6 @@ __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
     r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.x;
     r.v[0] = B.y; r.v[1] = B.z; r.v[2] = B.w;
     return r;
-}
-// scalar-path record fetch (j is wave-uniform)
-__device__ __forceinline__ Rec load_rec(const float4* __restrict__ rec, uint32_t j) {
-    return make_rec(rec[2 * j], rec[2 * j + 1]);
 }
 
 __device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mask below this lane
@@ -679,21 +611,8 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void bin
         SPoint sp = {0.f, 0.f, 0u};
         if (valid) sp = pv.spts[base + lane];
         float s[2] = {sp.x, sp.y};
-#if PIGS_FWD_CELL_RECT
-        // the cell's own rectangle instead of the tight box of its points: a few percent more
-        // accepted Gaussians, but the traversal no longer waits for the points to arrive
-        (void)INF;
-        const SampleGrid sg = pv.params->sg;
-        const int hx = sg.nx >> 1;
-        const int cx = 2 * (int)((cell >> 2) % (uint32_t)hx) + (int)(cell & 1u);
-        const int cy = 2 * (int)((cell >> 2) / (uint32_t)hx) + (int)((cell >> 1) & 1u);
-        const float cw = __builtin_amdgcn_rcpf(sg.inv_w), eps = 1e-5f * cw;
-        const float bx0 = sg.ox + cw * (float)cx - eps, bx1 = sg.ox + cw * (float)(cx + 1) + eps;
-        const float by0 = sg.oy + cw * (float)cy - eps, by1 = sg.oy + cw * (float)(cy + 1) + eps;
-#else
         const float bx0 = wave_min_dpp(valid ? s[0] : INF), bx1 = wave_max_dpp(valid ? s[0] : -INF);
         const float by0 = wave_min_dpp(valid ? s[1] : INF), by1 = wave_max_dpp(valid ? s[1] : -INF);
-#endif
         if (!valid) { s[0] = bx0; s[1] = by0; }
 
         float acc[L::N];
@@ -703,13 +622,8 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void bin
 #if PIGS_STAMPS
         const unsigned long long T1 = stamp();
 #endif
-#if PIGS_FWD_TRAVERSE == 0
-        for_each_candidate_step(pv, gg, level_mask, bx0, by0, bx1, by1, lane,
-                 [&](uint32_t, const float4 A, const float4 B, uint64_t mask) {
-#else
         traverse(pv, gg, level_mask, bx0, by0, bx1, by1, lane, lds,
                  [&](const float4 A, const float4 B, uint64_t mask, uint32_t) {
-#endif
             const int cnt = __builtin_popcountll(mask);
             if (qn + cnt > QCAP) {
                 evaluate_queue<C, MASK>(acc, s, lds.queue, qn, lane);
