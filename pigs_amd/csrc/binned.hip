@@ -91,6 +91,7 @@ struct BuildArgs {
     uint2* skey;          // per point    {cell id,  rank inside the cell}
     float4* rec;
     float4* gbox;
+    float* gacc;
     uint32_t* g2o;
     SPoint* spts;
     const float* means;
@@ -357,6 +358,10 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
             a.gbox[pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], hx * 1.0001f, hy * 1.0001f);
         }
         a.g2o[pos] = i;
+        // the backward's scratch starts zeroed (and plan_unpermute_kernel re-zeroes what it
+        // reads), so the backward needs no memset launch
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a.gacc[(size_t)k * a.N + pos] = 0.f;
     }
     if (!gpart && i < a.M) {
         const uint2 kr = a.skey[i];
@@ -827,12 +832,18 @@ __global__ __launch_bounds__(256) void plan_unpermute_kernel(PlanView pv, float*
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= pv.N) return;
     const uint32_t n = pv.g2o[j];
-    g_means[2 * n] = pv.gacc[(size_t)(BL::MU + 0) * pv.N + j];
-    g_means[2 * n + 1] = pv.gacc[(size_t)(BL::MU + 1) * pv.N + j];
+    float v[BL::N];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g_conics[3 * n + k] = pv.gacc[(size_t)(BL::CON + k) * pv.N + j];
+    for (int k = 0; k < BL::N; ++k) {
+        v[k] = pv.gacc[(size_t)k * pv.N + j];
+        pv.gacc[(size_t)k * pv.N + j] = 0.f;       // leave the scratch zeroed for the next backward
+    }
+    g_means[2 * n] = v[BL::MU + 0];
+    g_means[2 * n + 1] = v[BL::MU + 1];
 #pragma unroll
-    for (int k = 0; k < C; ++k) g_values[(size_t)C * n + k] = pv.gacc[(size_t)(BL::VAL + k) * pv.N + j];
+    for (int k = 0; k < 3; ++k) g_conics[3 * n + k] = v[BL::CON + k];
+#pragma unroll
+    for (int k = 0; k < C; ++k) g_values[(size_t)C * n + k] = v[BL::VAL + k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -893,6 +904,7 @@ int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, i
     a.skey = (uint2*)(b + p.off_skey);
     a.rec = (float4*)(b + p.off_rec);
     a.gbox = (float4*)(b + p.off_box);
+    a.gacc = (float*)(b + p.off_gacc);
     a.g2o = (uint32_t*)(b + p.off_g2o);
     a.spts = (SPoint*)(b + p.off_spts);
     a.means = (const float*)means; a.conics = (const float*)conics;
@@ -934,7 +946,6 @@ static int plan_backward_c(const PlanView& pv, int mask, const float* const* g, 
                            hipStream_t stream) {
     const dim3 grid(pv.scells_cap / 4), block(256);
     clear_hip_error();
-    if (hipMemsetAsync(pv.gacc, 0, sizeof(float) * 8 * (size_t)pv.N, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
 #define PIGS_CASE(MK)                                                                                         \
     case MK:                                                                                                  \
         hipLaunchKernelGGL((binned_backward_kernel<C, MK>), grid, block, 0, stream, pv, g[0], g[1], g[2], g[3]); \
