@@ -438,21 +438,25 @@ struct WaveLdsT {
 };
 using WaveLds = WaveLdsT<QCAP>;
 
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp_keep_f32(float v) {     // lanes without a source keep v
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                 CTRL, ROW_MASK, 0xF, false));
-}
+// Wave-wide min / max with the DPP modifier fused into the min (hipcc emits v_mov_dpp + a
+// canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  "s_nop 1"
+// covers the VALU-write -> DPP-read wait states inside the asm.  Result broadcast from lane 63.
+#define PIGS_DPP_REDUCE(OP)                                                                      \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                   \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                   \
+    "s_nop 1"
 __device__ __forceinline__ float wave_min_dpp(float v) {
-    v = fminf(v, dpp_keep_f32<0xB1>(v));
-    v = fminf(v, dpp_keep_f32<0x4E>(v));
-    v = fminf(v, dpp_keep_f32<0x141>(v));
-    v = fminf(v, dpp_keep_f32<0x140>(v));
-    v = fminf(v, dpp_keep_f32<0x142, 0xA>(v));
-    v = fminf(v, dpp_keep_f32<0x143, 0xC>(v));
+    asm volatile(PIGS_DPP_REDUCE("v_min_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
-__device__ __forceinline__ float wave_max_dpp(float v) { return -wave_min_dpp(-v); }
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    asm volatile(PIGS_DPP_REDUCE("v_max_f32_dpp") : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 
 template <int C, int MASK>
 __device__ __forceinline__ void evaluate_queue(float* acc, const float* s, float4 (*q)[2], int n, int lane) {
@@ -684,10 +688,13 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
     return a + b;     // rows 0,2: a[row] + a[row+1]; rows 1,3: b[row-1] + b[row]
 }
 __device__ __forceinline__ float row_sum(float v) {      // sum over the 16 lanes of a row, in every lane
-    v += dpp_f32<0xB1>(v);
-    v += dpp_f32<0x4E>(v);
-    v += dpp_f32<0x141>(v);
-    v += dpp_f32<0x140>(v);
+    asm volatile(
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 

@@ -303,13 +303,20 @@ __device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, 
                 eyy = fma_<T>(T(3) * k3, py, fma_<T>(k2, px, eyy));
             }
             acc[L::VAL + ch] = fma_<T>(g, F, acc[L::VAL + ch]);
-            A = fma_<T>(v[ch], F, A);
-            dAx = fma_<T>(v[ch], dFx, dAx);
-            dAy = fma_<T>(v[ch], dFy, dAy);
-            Exx = fma_<T>(v[ch], exx, Exx);
-            Exy = fma_<T>(v[ch], exy, Exy);
-            Eyy = fma_<T>(v[ch], eyy, Eyy);
+            if constexpr (C == 1) {
+                // one channel: v factors out of A, dA and E -- carry it in the weight instead
+                A = F; dAx = dFx; dAy = dFy; Exx = exx; Exy = exy; Eyy = eyy;
+            } else {
+                A = fma_<T>(v[ch], F, A);
+                dAx = fma_<T>(v[ch], dFx, dAx);
+                dAy = fma_<T>(v[ch], dFy, dAy);
+                Exx = fma_<T>(v[ch], exx, Exx);
+                Exy = fma_<T>(v[ch], exy, Exy);
+                Eyy = fma_<T>(v[ch], eyy, Eyy);
+            }
         }
+        const T g_ = g;
+        const T g = (C == 1) ? g_ * v[0] : g_;          // weight of the mean / conic terms
         // means: g (A p_l - (dA . C)_l)
         acc[L::MU + 0] = fma_<T>(g, fma_<T>(A, px, -fma_<T>(dAx, a, dAy * b)), acc[L::MU + 0]);
         acc[L::MU + 1] = fma_<T>(g, fma_<T>(A, py, -fma_<T>(dAx, b, dAy * c)), acc[L::MU + 1]);

@@ -16,8 +16,18 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;     // rows 0,2: a[row] + a[row+1]; rows 1,3: b[row-1] + b[row]
 }
-__device__ float row_sum(float v) {
+__device__ float row_sum_builtin(float v) {
     v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
+    return v;
+}
+__device__ float row_sum(float v) {      // the asm form used by binned.hip
+    asm volatile(
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 __global__ void k(float* o) {
