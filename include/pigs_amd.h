@@ -69,7 +69,7 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
                          void* g_means, void* g_conics, void* g_values, void* stream);
 
 /*
- * Binned ("plan") path -- float32, d = 2, c <= 3.  preprocess() builds a plan in a caller-owned
+ * Binned ("plan") path -- float32, d = 2, c <= 2.  preprocess() builds a plan in a caller-owned
  * device workspace: Gaussians binned by centre into a multi-level cell grid (packed, sorted
  * 32-byte records), sample points sorted into 64-point cells.  The sampling entry points then
  * evaluate, for every point, only the Gaussians whose q <= q_max ellipse reaches the point's

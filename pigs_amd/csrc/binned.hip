@@ -345,10 +345,11 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     if (gpart && i < a.N) {
         const uint2 kr = a.gkey[i];
         const uint32_t pos = a.starts[kr.x] + kr.y;
-        float v[3] = {0.f, 0.f, 0.f};
+        float v[2] = {0.f, 0.f};
         for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
+        // {mux, muy, a, b}, {b, c, v0, v1}: (a, b) and (b, c) are register pairs for packed math
         a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
-        a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 2], v[0], v[1], v[2]);
+        a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 1], a.conics[3 * i + 2], v[0], v[1]);
         {   // bounding box of the q <= q_max ellipse: half extents sqrt(q_max Sigma_xx), sqrt(q_max Sigma_yy)
             const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
             const float k = a.q_max / (ca * cc - cb * cb);
@@ -396,12 +397,12 @@ __device__ __forceinline__ bool ellipse_reaches_rect(float4 A, float cc, float x
 // `batch_end(j0, mask)` around each step of 64 candidates.
 // ------------------------------------------------------------------------------------------
 struct Rec {
-    float mu[2], con[3], v[3];
+    float mu[2], con[3], v[2];
 };
 __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
     Rec r;
-    r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.x;
-    r.v[0] = B.y; r.v[1] = B.z; r.v[2] = B.w;
+    r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.y;
+    r.v[0] = B.z; r.v[1] = B.w;
     return r;
 }
 
@@ -458,6 +459,30 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// One record on one point for c = 1, orders 0..2, written on register PAIRS so that hipcc emits
+// v_pk_* without the v_mov shuffles its SLP packing of the scalar form needs: the record keeps
+// (a, b) and (b, c) adjacent, the accumulators are (ux, uy), (hxx, hxy) and scalars u, hyy.
+struct AccPk {
+    float u, hyy;
+    f2 g1, h2;      // (ux, uy), (hxx, hxy); signs applied on store
+};
+__device__ __forceinline__ void accumulate_pk(AccPk& a, f2 s, const float4 A, const float4 B) {
+    const f2 mu = {A.x, A.y}, ab = {A.z, A.w}, bc = {B.x, B.y};
+    const f2 d = s - mu;
+    f2 p = ab * d.x;
+    p = __builtin_elementwise_fma(bc, (f2){d.y, d.y}, p);            // p = C d
+    const float q = fma_<float>(d.y, p.y, d.x * p.x);
+    const float w = B.z * exp_neg_half<float>(q);
+    const f2 t = __builtin_elementwise_fma((f2){p.x, p.x}, p, -ab);   // (px px - a, px py - b)
+    const float tyy = fma_<float>(p.y, p.y, -B.y);
+    a.u += w;
+    a.g1 = __builtin_elementwise_fma(p, (f2){w, w}, a.g1);
+    a.h2 = __builtin_elementwise_fma(t, (f2){w, w}, a.h2);
+    a.hyy = fma_<float>(tyy, w, a.hyy);
+}
+
 template <int C, int MASK>
 __device__ __forceinline__ void evaluate_queue(float* acc, const float* s, float4 (*q)[2], int n, int lane) {
     constexpr int U = PIGS_FWD_UNROLL;       // records per iteration (independent chains for ILP)
@@ -469,17 +494,34 @@ __device__ __forceinline__ void evaluate_queue(float* acc, const float* s, float
     float4 a[U], b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { a[u] = q[u][0]; b[u] = q[u][1]; }
-    for (int k = 0; k < n; k += U) {
-        float4 na[U], nb[U];
+    if constexpr (C == 1 && MASK == 7) {
+        using L = FwdLayout<2, 1, 7>;
+        AccPk A = {acc[L::O0], acc[L::O2 + 2], {acc[L::O1], acc[L::O1 + 1]}, {acc[L::O2], acc[L::O2 + 1]}};
+        const f2 sp = {s[0], s[1]};
+        for (int k = 0; k < n; k += U) {
+            float4 na[U], nb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { na[u] = q[k + U + u][0]; nb[u] = q[k + U + u][1]; }
+            for (int u = 0; u < U; ++u) { na[u] = q[k + U + u][0]; nb[u] = q[k + U + u][1]; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const Rec r = make_rec(a[u], b[u]);
-            fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v);
+            for (int u = 0; u < U; ++u) accumulate_pk(A, sp, a[u], b[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = na[u]; b[u] = nb[u]; }
         }
+        acc[L::O0] = A.u; acc[L::O1] = A.g1.x; acc[L::O1 + 1] = A.g1.y;
+        acc[L::O2] = A.h2.x; acc[L::O2 + 1] = A.h2.y; acc[L::O2 + 2] = A.hyy;
+    } else {
+        for (int k = 0; k < n; k += U) {
+            float4 na[U], nb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { a[u] = na[u]; b[u] = nb[u]; }
+            for (int u = 0; u < U; ++u) { na[u] = q[k + U + u][0]; nb[u] = q[k + U + u][1]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const Rec r = make_rec(a[u], b[u]);
+                fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = na[u]; b[u] = nb[u]; }
+        }
     }
 }
 
@@ -552,10 +594,10 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
                 const float4 A0 = pv.rec[2 * i0], B0 = pv.rec[2 * i0 + 1];
                 float4 A1 = A0, B1 = B0;
                 if (b0 + 64 < cn) { A1 = pv.rec[2 * i1]; B1 = pv.rec[2 * i1 + 1]; }
-                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.x, bx0, by0, bx1, by1, pv.q_max));
+                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.y, bx0, by0, bx1, by1, pv.q_max));
                 if (m0) batch(A0, B0, m0, i0);
                 if (b0 + 64 < cn) {
-                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.x, bx0, by0, bx1, by1, pv.q_max));
+                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.y, bx0, by0, bx1, by1, pv.q_max));
                     if (m1) batch(A1, B1, m1, i1);
                 }
             }
@@ -875,7 +917,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
 }
 
 static bool plan_supported(int64_t N, int64_t M, int c) {
-    return N >= 1 && M >= 1 && c >= 1 && c <= 3 && N < (1LL << 30) && M < (1LL << 31) - 64 &&
+    return N >= 1 && M >= 1 && c >= 1 && c <= 2 && N < (1LL << 30) && M < (1LL << 31) - 64 &&
            N + M < (1LL << 32) - 1;
 }
 
@@ -984,7 +1026,6 @@ int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q
     switch (c) {
         case 1: return plan_forward_c<1>(pv, cm, o, stream);
         case 2: return plan_forward_c<2>(pv, cm, o, stream);
-        case 3: return plan_forward_c<3>(pv, cm, o, stream);
     }
     return PIGS_ERR_UNSUPPORTED;
 }
@@ -1001,7 +1042,6 @@ int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float 
     switch (c) {
         case 1: return plan_backward_c<1>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
         case 2: return plan_backward_c<2>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
-        case 3: return plan_backward_c<3>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
     }
     return PIGS_ERR_UNSUPPORTED;
 }

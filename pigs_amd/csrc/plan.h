@@ -139,7 +139,7 @@ struct PlanView {
     const PlanParams* params;
     const uint32_t* starts;       // [ncounts + 1] exclusive scan of the cell counters: Gaussian cells at
                                   // [0, gcells), sample cells at [sbase, sbase + scells_cap)
-    const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {c, v0, v1, v2}  (c <= 3)
+    const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {b, c, v0, v1}  (c <= 2)
     const float4* gbox;           // [N] sorted: {mux, muy, hx, hy} = centre and half extents of the q <= q_max ellipse
     const uint32_t* g2o;          // sorted Gaussian -> original index
     const SPoint* spts;           // sorted points: coordinates + original index

@@ -90,7 +90,7 @@ class Plan:
 
     @staticmethod
     def supported(means, values, samples):
-        return (means.dtype == torch.float32 and means.shape[1] == 2 and 1 <= values.shape[1] <= 3
+        return (means.dtype == torch.float32 and means.shape[1] == 2 and 1 <= values.shape[1] <= 2
                 and means.shape[0] >= 1 and samples.shape[0] >= 1)
 
 
@@ -190,7 +190,7 @@ class GaussianSampler:
     ``backend`` (extension, keyword only): ``"dense"`` evaluates every (point, Gaussian) pair --
     the reference's dense semantics exactly; ``"binned"`` builds the culling plan in ``preprocess``
     and drops pairs with q > ``q_max`` (relative truncation below exp(-q_max/2)); ``"auto"`` picks
-    binned for float32, d = 2, c <= 3 once N*M >= 2**26 pairs, where the plan pays for itself.
+    binned for float32, d = 2, c <= 2 once N*M >= 2**26 pairs, where the plan pays for itself.
 
     ``fuse`` (extension, keyword only) controls how many derivative orders one launch computes:
     ``"auto"`` -- the first ``sample_*`` call after a ``preprocess`` computes orders 0..2 in one
@@ -278,7 +278,7 @@ class GaussianSampler:
             if self.debug:
                 torch.cuda.synchronize(means.device)
         elif self.backend == "binned" and N > 0 and sc.shape[0] > 0:
-            raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 3")
+            raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 2")
 
     def _scratch_for(self, device):
         """The build's persistent scratch (zero once, left zero by every build), per device and

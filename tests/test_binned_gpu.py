@@ -64,7 +64,7 @@ def check_case(Sampler, means, con, values, samples, orders=(0, 1, 2, 3), bwd=Tr
     assert rel(t[2].grad, ec) < gtol, ("conics", rel(t[2].grad, ec))
 
 
-@pytest.mark.parametrize("N,M,c", [(1, 1, 1), (7, 3, 2), (500, 2000, 1), (3000, 5000, 2), (2048, 4096, 3)])
+@pytest.mark.parametrize("N,M,c", [(1, 1, 1), (7, 3, 2), (500, 2000, 1), (3000, 5000, 2), (2048, 4096, 2)])
 def test_random_points_and_gaussians(Sampler, N, M, c):
     rng = np.random.default_rng(N + M)
     means, con, values = random_gaussians(rng, N, c)

@@ -18,7 +18,7 @@ def Sampler(hip_lib):
 def make_case(rng):
     N = int(rng.integers(1, 3000))
     M = int(rng.integers(1, 6000))
-    c = int(rng.integers(1, 4))
+    c = int(rng.integers(1, 3))
     span = 10.0 ** rng.uniform(-1, 1.5)                       # domain size 0.1 .. 30
     centre = rng.uniform(-5, 5, 2)
     means = centre + rng.uniform(-span, span, (N, 2))
