@@ -45,7 +45,7 @@ enum pigs_status {
     PIGS_OK = 0,
     PIGS_ERR_INVALID = 1,      /* bad argument (negative size, null required pointer, ...) */
     PIGS_ERR_UNSUPPORTED = 2,  /* d / c / dtype / mask combination not compiled            */
-    PIGS_ERR_LAUNCH = 3,       /* HIP reported a launch / memset error                     */
+    PIGS_ERR_LAUNCH = 3,       /* HIP reported a launch error                              */
     PIGS_ERR_WORKSPACE = 4     /* workspace too small for the plan                         */
 };
 

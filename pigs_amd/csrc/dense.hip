@@ -171,6 +171,17 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
     }
 }
 
+// zero three word arrays (the atomically accumulated gradient buffers) in one launch
+__global__ __launch_bounds__(256) void zero_grads_kernel(uint32_t* __restrict__ p0, uint64_t n0, uint32_t* __restrict__ p1,
+                                                         uint64_t n1, uint32_t* __restrict__ p2, uint64_t n2) {
+    const uint64_t total = n0 + n1 + n2;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        if (i < n0) p0[i] = 0u;
+        else if (i < n0 + n1) p1[i - n0] = 0u;
+        else p2[i - n0 - n1] = 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host-side launchers
 // ------------------------------------------------------------------------------------------
@@ -209,11 +220,19 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     if (gblocks > 0x7fffffffLL) return PIGS_ERR_INVALID;
     clear_hip_error();
     T* gm = (T*)a.g_means; T* gc = (T*)a.g_conics; T* gv = (T*)a.g_values;
+    // The gradient buffers are zeroed by a kernel of our own, one launch for all three:
+    // hipMemsetAsync nodes replayed inside a hipGraph were seen (ROCm 7.2) to fill with a stale
+    // 16-byte pattern now and then (tests/test_graph_gpu.py), and this is one launch, not three.
+    auto zero_grads = [&]() {
+        const uint64_t wm = sizeof(T) / 4 * (uint64_t)a.N * D, wc = sizeof(T) / 4 * (uint64_t)a.N * NF,
+                       wv = sizeof(T) / 4 * (uint64_t)a.N * C;
+        const uint64_t blocks = (wm + wc + wv + 1023) / 1024;
+        hipLaunchKernelGGL(zero_grads_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream,
+                           (uint32_t*)gm, wm, (uint32_t*)gc, wc, (uint32_t*)gv, wv);
+    };
     if (a.M == 0) {
-        if (hipMemsetAsync(gm, 0, sizeof(T) * a.N * D, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
-        if (hipMemsetAsync(gc, 0, sizeof(T) * a.N * NF, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
-        if (hipMemsetAsync(gv, 0, sizeof(T) * a.N * C, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
-        return PIGS_OK;
+        zero_grads();
+        return launch_status();
     }
     // split the point range over gridDim.y so that ~2048 workgroups exist; each wave should
     // still see >= 64 points
@@ -222,11 +241,7 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     if (ysplit > max_split) ysplit = max_split;
     if (ysplit < 1) ysplit = 1;
     if (ysplit > 65535) ysplit = 65535;
-    if (ysplit > 1) {
-        if (hipMemsetAsync(gm, 0, sizeof(T) * a.N * D, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
-        if (hipMemsetAsync(gc, 0, sizeof(T) * a.N * NF, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
-        if (hipMemsetAsync(gv, 0, sizeof(T) * a.N * C, stream) != hipSuccess) return PIGS_ERR_LAUNCH;
-    }
+    if (ysplit > 1) zero_grads();
     hipLaunchKernelGGL((dense_backward_kernel<T, D, C, MASK, 4>), dim3((unsigned)gblocks, (unsigned)ysplit), dim3(256),
                        0, stream, a.N, a.M, (const T*)a.means, (const T*)a.conics, (const T*)a.values,
                        (const T*)a.samples, (const T*)a.gout[0], (const T*)a.gout[1], (const T*)a.gout[2],

@@ -32,4 +32,20 @@ for n, M in ((20, 1024), (40, 1024), (40, 4096), (90, 65536)):
         for _ in range(50):
             f()
         torch.cuda.synchronize()
-        print(f"N={n*n:5d} M={M:6d} {name:>14}: {(time.perf_counter()-t0)/50*1e6:8.1f} us/call  (plan: {s._plan is not None})", flush=True)
+        eager = (time.perf_counter() - t0) / 50 * 1e6
+        # the same call captured once into a hipGraph (no entry point allocates or synchronises)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            f()
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            graph.replay()
+        torch.cuda.synchronize()
+        replay = (time.perf_counter() - t0) / 50 * 1e6
+        print(f"N={n*n:5d} M={M:6d} {name:>14}: eager {eager:8.1f} us/call   hipGraph replay {replay:8.1f} us/call"
+              f"  (plan: {s._plan is not None})", flush=True)
