@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 1
+#define PIGS_ABI_VERSION 2
 
 enum pigs_status {
     PIGS_OK = 0,
@@ -81,13 +81,8 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
  */
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsupported sizes */
 
-/* `scratch`: a caller-owned device buffer of pigs_plan_scratch_bytes() bytes that is ALL ZERO before
- * the first build; every build leaves it zero again (so it needs no per-call initialisation).
- * Builds sharing one scratch must be stream ordered. */
-size_t pigs_plan_scratch_bytes(void);
-
-int pigs_plan_build(void* workspace, size_t workspace_bytes, void* scratch, int64_t N, int64_t M, int c,
-                    float q_max, const void* means, const void* conics, const void* values,
+int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
+                    const void* means, const void* conics, const void* values,
                     const void* samples, void* stream);
 
 int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIGS_AMD_LIB") or os.path.join(HERE, "libpigs_amd.so")
 
 PIGS_F32, PIGS_F64 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -29,8 +29,7 @@ SIGNATURES = {
     "pigs_sample_forward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp]),
     "pigs_sample_backward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp] * 3 + [_vp]),
     "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
-    "pigs_plan_scratch_bytes": (ctypes.c_size_t, []),
-    "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _vp, _i64, _i64, _i, ctypes.c_float] + [_vp] * 4 + [_vp]),
+    "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float] + [_vp] * 4 + [_vp]),
     "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4 + [_vp]),
     "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4
                            + [_vp] * 3 + [_vp]),

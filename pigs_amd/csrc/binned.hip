@@ -80,7 +80,6 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // preprocess kernels
 // ------------------------------------------------------------------------------------------
 struct BuildArgs {
-    PlanScratch* scratch;
     PlanParams* params;
     BoxPartial* boxes;    // [PLAN_BBOX_BLOCKS]
     uint32_t* counts;     // Gaussian cell counters at [0, gcells), sample cell counters at
@@ -252,11 +251,6 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
         base = __shfl(base, r.start);
         if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
-        // one atomicOr per wave, and only for levels not yet recorded
-        uint32_t lv = valid ? 1u << l : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lv |= __shfl_xor(lv, o);
-        if (lane == 0 && (lv & ~*(volatile uint32_t*)&a.scratch->level_mask)) atomicOr(&a.scratch->level_mask, lv);
     } else {
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
         uint32_t id[4], base[4];
@@ -331,16 +325,18 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     ((uint4*)a.starts)[q] = o4;      // counters beyond ncounts are zero: starts[ncounts] = total
 }
 
-// Launch 4: scatter into sorted order (no atomics: position = cell start + rank), publish the
-// level mask and hand the scratch back zeroed.
+// Launch 4: scatter into sorted order (no atomics: position = cell start + rank) and publish the
+// level mask.
 __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     const uint32_t gblocks = (a.N + 255) / 256;
     const bool gpart = blockIdx.x < gblocks;
     const uint32_t i = (gpart ? blockIdx.x : blockIdx.x - gblocks) * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.params->level_mask = a.scratch->level_mask;
-        uint32_t* z = (uint32_t*)a.scratch;
-        for (uint32_t k = 0; k < sizeof(PlanScratch) / 4; ++k) z[k] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // level l holds a Gaussian iff its cells' scanned range is not empty (no atomics, no scratch)
+        const int l = (int)threadIdx.x;
+        const bool occ = l < a.L && a.starts[a.level_off[l + 1 <= a.L ? l + 1 : a.L]] != a.starts[a.level_off[l < a.L ? l : 0]];
+        const uint64_t m = __ballot(occ);
+        if (threadIdx.x == 0) a.params->level_mask = (uint32_t)m;
     }
     if (gpart && i < a.N) {
         const uint2 kr = a.gkey[i];
@@ -921,7 +917,6 @@ static bool plan_supported(int64_t N, int64_t M, int c) {
            N + M < (1LL << 32) - 1;
 }
 
-size_t plan_scratch_bytes() { return PLAN_SCRATCH_BYTES; }
 
 #if PIGS_STAMPS
 extern "C" int pigs_debug_stamps(void* host_out) {
@@ -934,16 +929,15 @@ size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
     return make_plan_layout(N, M, c).total_bytes;
 }
 
-int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, int c, float q_max,
+int plan_build(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max,
                const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
-    if (!(q_max > 0.f) || !scratch) return PIGS_ERR_INVALID;
+    if (!(q_max > 0.f)) return PIGS_ERR_INVALID;
     const PlanLayout p = make_plan_layout(N, M, c);
     if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
     char* b = (char*)ws;
     BuildArgs a{};
-    a.scratch = (PlanScratch*)scratch;
     a.params = (PlanParams*)(b + p.off_params);
     a.boxes = (BoxPartial*)(b + p.off_boxes);
     a.counts = (uint32_t*)(b + p.off_counts);

@@ -69,14 +69,12 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
 
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c) { return plan_workspace_bytes(N, M, c); }
 
-size_t pigs_plan_scratch_bytes(void) { return plan_scratch_bytes(); }
-
-int pigs_plan_build(void* workspace, size_t workspace_bytes, void* scratch, int64_t N, int64_t M, int c,
+int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c,
                     float q_max, const void* means, const void* conics, const void* values, const void* samples,
                     void* stream) {
     if (N < 0 || M < 0 || c < 1) return PIGS_ERR_INVALID;
     if (!means || !conics || !values || !samples) return PIGS_ERR_INVALID;
-    return plan_build(workspace, workspace_bytes, scratch, N, M, c, q_max, means, conics, values, samples,
+    return plan_build(workspace, workspace_bytes, N, M, c, q_max, means, conics, values, samples,
                       (hipStream_t)stream);
 }
 

@@ -20,8 +20,7 @@ int dense_dispatch(bool backward, const SampleArgs& a, hipStream_t stream);
 
 // binned.hip
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c);
-size_t plan_scratch_bytes();
-int plan_build(void* ws, size_t ws_bytes, void* scratch, int64_t N, int64_t M, int c, float q_max,
+int plan_build(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max,
                const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream);
 int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask, void* const* out,

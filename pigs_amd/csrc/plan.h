@@ -34,15 +34,6 @@ constexpr int PLAN_POINTS_PER_CELL = 63;   // target occupancy of a 64-lane samp
                                             // yields cells of 49..64 points (never a second pass); for Poisson
                                             // counts the short second passes cost about what emptier cells would
 
-// Device-resident header (first bytes of the workspace), written by the preprocess kernels.
-// Caller-provided persistent scratch of the build (PLAN_SCRATCH_BYTES, zero before the first
-// build; every build leaves it zero again, so builds sharing one scratch must be stream ordered).
-struct PlanScratch {
-    uint32_t level_mask; // bit l set = level l holds at least one Gaussian
-    uint32_t pad1[63];
-};
-constexpr size_t PLAN_SCRATCH_BYTES = sizeof(PlanScratch);
-
 // Per-workgroup partial bounding boxes written by the first build kernel (plain stores; same-
 // address atomics serialise at ~10 ns each, so no atomics here) and reduced again by every
 // workgroup of the second.

@@ -72,7 +72,7 @@ class Plan:
 
     __slots__ = ("workspace", "N", "M", "c", "q_max")
 
-    def __init__(self, means, values, conics, samples, q_max, scratch):
+    def __init__(self, means, values, conics, samples, q_max):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
         key = (self.N, self.M, self.c)
@@ -83,7 +83,7 @@ class Plan:
             raise _lib.PigsError(f"binned path does not support N={self.N} M={self.M} c={self.c}")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
         with _on_device(means.device):
-            rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, _ptr(scratch), self.N, self.M, self.c, self.q_max,
+            rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, self.N, self.M, self.c, self.q_max,
                                      _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
                                      _stream(means.device))
         _lib.check(rc, "pigs_plan_build")
@@ -215,7 +215,6 @@ class GaussianSampler:
         self.q_max = float(q_max)
         self._inputs = None
         self._plan = None
-        self._scratch = {}
         self._cache = {}
         _lib.load()  # fail at construction, not at first use, if the HIP library is missing
 
@@ -274,19 +273,11 @@ class GaussianSampler:
             self.backend == "auto" and N * sc.shape[0] >= self.BINNED_AUTO_MIN_PAIRS)
         if use_plan and Plan.supported(mc, vc, sc):
             with torch.no_grad():
-                self._plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, self.q_max, self._scratch_for(mc.device))
+                self._plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, self.q_max)
             if self.debug:
                 torch.cuda.synchronize(means.device)
         elif self.backend == "binned" and N > 0 and sc.shape[0] > 0:
             raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 2")
-
-    def _scratch_for(self, device):
-        """The build's persistent scratch (zero once, left zero by every build), per device and
-        per stream: builds that share a scratch must be stream ordered."""
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
-        if key not in self._scratch:
-            self._scratch[key] = torch.zeros(_lib.load().pigs_plan_scratch_bytes(), dtype=torch.uint8, device=device)
-        return self._scratch[key]
 
     # ------------------------------------------------------------------ sampling
     def _require_inputs(self):

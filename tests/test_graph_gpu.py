@@ -41,7 +41,7 @@ def test_captured_step_replays_on_new_parameters(hip_lib, backend, n, res):
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):          # warm up on the capture stream: scratch, library load
+    with torch.cuda.stream(side):          # warm up on the capture stream: library load, allocator, autograd
         step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
