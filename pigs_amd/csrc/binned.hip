@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             const float inv_s = 1.f / s;
             const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
             const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
-            key = a.level_off[l] + (uint32_t)(cy * G + cx);
+            key = a.level_off[l] + ((uint32_t)(cy * G + cx) << level_shift((uint32_t)(G * G)));
         }
         const Run r = run_of(key, lane);
         uint32_t base = 0;
@@ -537,8 +537,11 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
     const int cy0 = (int)clampf(floorf((by0 - gg.oy) * inv_s) - 1.f, 0.f, gmax);
     const int cy1 = (int)clampf(floorf((by1 - gg.oy) * inv_s) + 1.f, 0.f, gmax);
     const int nr = occ ? cy1 - cy0 + 1 : 0;
-    // first cell of level l = sum_{k<l} (G0 >> k)^2 = 4 (G0^2 - (G0 >> l)^2) / 3   (G0 a power of two)
-    const uint32_t loff = (uint32_t)(4 * (pv.G0 * pv.G0 - G * G) / 3);
+    // first counter of this lane's level (kernel argument table -> lane select) and the level's counter spacing
+    uint32_t loff = 0;
+#pragma unroll
+    for (int l = 1; l < PLAN_MAX_LEVELS; ++l) loff = lane == l ? pv.level_off[l] : loff;
+    const int csh = level_shift((uint32_t)(G * G));
     int inc = nr;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {           // levels live in lanes 0..11
@@ -552,9 +555,9 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
         for (int k = 0; k < nr; ++k) {
             const int r = cum + k - r0;
             if (r >= 0 && r < 64) {
-                const uint32_t row = loff + (uint32_t)((cy0 + k) * G);
-                lds.row_a0[r] = row + (uint32_t)cx0;
-                lds.row_a1[r] = row + (uint32_t)cx1 + 1u;
+                const uint32_t row = (uint32_t)((cy0 + k) * G);
+                lds.row_a0[r] = loff + ((row + (uint32_t)cx0) << csh);
+                lds.row_a1[r] = loff + ((row + (uint32_t)cx1 + 1u) << csh);
             }
         }
         const int nrow = R - r0 < 64 ? R - r0 : 64;

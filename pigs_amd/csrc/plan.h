@@ -70,7 +70,7 @@ struct PlanLayout {
     int64_t N, M;
     int c;
     int G0, L;                 // finest Gaussian grid is G0 x G0; L levels
-    uint32_t gcells;           // total Gaussian cells over all levels
+    uint32_t gcells;           // total Gaussian cell counters over all levels (padded: level_shift)
     uint32_t scells_cap;       // capacity (upper bound) of sample cells, multiple of 4
     uint32_t sbase;            // index of the first sample-cell counter (gcells rounded up to a 128-B line)
     uint32_t ncounts;          // sbase + scells_cap
@@ -81,6 +81,17 @@ struct PlanLayout {
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Counter spacing of a level with `cells` cells: device-scope atomics on one 128-byte line
+// serialise (~10 ns each; tools/ubench/atomics2.hip: 1 280 packed counters take 5 atomics/ns,
+// 128 bytes apart 25/ns, the chip's ceiling), and the coarse levels have few cells but can
+// hold most Gaussians -- so a level's counters are spread over at least 256 lines (up to one
+// line per counter).  The padding counters stay zero; the scan sums over them unchanged.
+__host__ __device__ inline int level_shift(uint32_t cells) {
+    int sh = 0;
+    while (sh < 5 && (cells << sh) < 8192u) ++sh;
+    return sh;
+}
 
 inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     PlanLayout p{};
@@ -95,7 +106,7 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     for (int l = 0; l < p.L; ++l) {
         p.level_off[l] = off;
         const uint32_t gl = (uint32_t)(g >> l);
-        off += gl * gl;
+        off += (gl * gl) << level_shift(gl * gl);
     }
     p.level_off[p.L] = off;
     p.gcells = off;
