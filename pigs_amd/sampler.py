@@ -200,7 +200,7 @@ class GaussianSampler:
     """
 
     FUSE_AUTO_MAX_POINTS = 1 << 16
-    BINNED_AUTO_MIN_PAIRS = 1 << 26     # dense: ~1.2e12 pairs/s; the plan costs ~40 us to build
+    BINNED_AUTO_MIN_PAIRS = 1 << 26     # dense: ~1.2e12 pairs/s; the plan costs ~32 us to build
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0):
         if fuse not in ("auto", "all", "none"):
