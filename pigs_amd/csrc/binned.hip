@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.params->gg = g;
         a.params->sg = sg;
+#pragma unroll
+        for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
     }
     // Gaussian workgroups first, sample workgroups after them: the two halves are independent
     // latency chains (load -> returning atomic -> store) and run concurrently on different CUs
@@ -402,6 +404,26 @@ __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
     return r;
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (workgroup i runs on XCD i % 8) and every
+// XCD has its own L2.  Cell ids follow the domain row by row, so inside every group of
+// 8 * PIGS_XCD_CHUNK consecutive cell blocks XCD x takes the x-th contiguous run of PIGS_XCD_CHUNK
+// blocks: each L2 then holds the Gaussian records of a strip of the domain instead of all of them,
+// while the launch still sweeps the domain once from top to bottom.  Bijective for any grid size
+// (blocks behind the last whole group keep their index).  0 = no remapping.
+#ifndef PIGS_XCD_CHUNK
+#define PIGS_XCD_CHUNK 256
+#endif
+__device__ __forceinline__ uint32_t xcd_block() {
+#if PIGS_XCD_CHUNK > 0
+    constexpr uint32_t GROUP = 8u * PIGS_XCD_CHUNK;
+    const uint32_t b = blockIdx.x, g = b / GROUP, r = b % GROUP;
+    if ((g + 1) * GROUP > gridDim.x) return b;
+    return g * GROUP + (r & 7u) * PIGS_XCD_CHUNK + (r >> 3);
+#else
+    return blockIdx.x;
+#endif
+}
+
 __device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mask below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -524,8 +546,9 @@ __device__ __forceinline__ void evaluate_queue(float* acc, const float* s, float
 // Steps 3-4 for one pass.  `batch(A, B, mask, j)` is called for every step with accepted
 // candidates (A, B: this lane's record; j: its sorted Gaussian index).
 template <typename Lds, typename Batch>
-__device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask, float bx0,
-                                         float by0, float bx1, float by1, int lane, Lds& lds, Batch&& batch) {
+__device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask, uint32_t loff,
+                                         float bx0, float by0, float bx1, float by1, int lane, Lds& lds,
+                                         Batch&& batch) {
     // 3. lane = level: rectangle of cells within one cell of the box; rows scanned over lanes
     const bool occ = lane < pv.L && (level_mask >> lane & 1u);
     const int sh = lane < pv.L ? lane : 0;
@@ -537,11 +560,7 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
     const int cy0 = (int)clampf(floorf((by0 - gg.oy) * inv_s) - 1.f, 0.f, gmax);
     const int cy1 = (int)clampf(floorf((by1 - gg.oy) * inv_s) + 1.f, 0.f, gmax);
     const int nr = occ ? cy1 - cy0 + 1 : 0;
-    // first counter of this lane's level (kernel argument table -> lane select) and the level's counter spacing
-    uint32_t loff = 0;
-#pragma unroll
-    for (int l = 1; l < PLAN_MAX_LEVELS; ++l) loff = lane == l ? pv.level_off[l] : loff;
-    const int csh = level_shift((uint32_t)(G * G));
+    const int csh = level_shift((uint32_t)(G * G));      // the level's counter spacing
     int inc = nr;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {           // levels live in lanes 0..11
@@ -639,8 +658,15 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
     }
 }
 
+// register budget: 6 waves/SIMD (80 VGPRs) for up to 10 accumulators per point, fewer waves for the
+// wide variants (c = 2 with orders up to 3: 12-20 accumulators) so that they do not spill
 template <int C, int MASK>
-__global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void binned_forward_kernel(
+constexpr int fwd_waves() {
+    constexpr int n = FwdLayout<2, C, MASK>::N;
+    return n > 12 ? 4 : (n > 10 || (C == 1 && MASK == 2)) ? 5 : PIGS_FWD_WAVES;   // <1,2>: 5 spilled VGPRs at 80
+}
+template <int C, int MASK>
+__global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, (fwd_waves<C, MASK>())) void binned_forward_kernel(
     PlanView pv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3) {
     using L = FwdLayout<2, C, MASK>;
     __shared__ WaveLds lds_all[PIGS_FWD_BLOCK_WAVES];
@@ -649,8 +675,9 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void bin
     WaveLds& lds = lds_all[wave];
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
+    const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
     const float INF = __builtin_huge_valf();
-    const uint32_t cell = blockIdx.x * PIGS_FWD_BLOCK_WAVES + (uint32_t)wave;
+    const uint32_t cell = xcd_block() * PIGS_FWD_BLOCK_WAVES + (uint32_t)wave;
     const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
     const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
 #if PIGS_STAMPS
@@ -672,7 +699,7 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, PIGS_FWD_WAVES) void bin
 #if PIGS_STAMPS
         const unsigned long long T1 = stamp();
 #endif
-        traverse(pv, gg, level_mask, bx0, by0, bx1, by1, lane, lds,
+        traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds,
                  [&](const float4 A, const float4 B, uint64_t mask, uint32_t) {
             const int cnt = __builtin_popcountll(mask);
             if (qn + cnt > QCAP) {
@@ -816,20 +843,23 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
 }
 
 template <int C, int MASK>
-__global__ __launch_bounds__(256, PIGS_BWD_WAVES) void binned_backward_kernel(PlanView pv, const float* __restrict__ G0p,
+constexpr int bwd_waves() { return (C == 2 && MASK == 15) ? 3 : PIGS_BWD_WAVES; }   // 3 waves: no spills
+template <int C, int MASK>
+__global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void binned_backward_kernel(PlanView pv, const float* __restrict__ G0p,
                                                               const float* __restrict__ G1p,
                                                               const float* __restrict__ G2p,
                                                               const float* __restrict__ G3p) {
     __shared__ WaveLdsBwd lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t cell = blockIdx.x * 4 + (uint32_t)wave;
+    const uint32_t cell = xcd_block() * 4 + (uint32_t)wave;
     const uint32_t sbeg = pv.starts[pv.sbase + cell] - pv.N;
     const uint32_t send = pv.starts[pv.sbase + cell + 1] - pv.N;
     if (sbeg >= send) return;
     WaveLdsBwd& lds = lds_all[wave];
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
+    const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
     const float INF = __builtin_huge_valf();
 
     for (uint32_t base = sbeg; base < send; base += 64) {
@@ -853,7 +883,7 @@ __global__ __launch_bounds__(256, PIGS_BWD_WAVES) void binned_backward_kernel(Pl
             }
         }
         int qn = 0;
-        traverse(pv, gg, level_mask, bx0, by0, bx1, by1, lane, lds.t,
+        traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.t,
                  [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
             const int cnt = __builtin_popcountll(mask);
             if (qn + cnt > QCAP_BWD) {

@@ -61,7 +61,8 @@ struct PlanParams {
     GaussGrid gg;
     SampleGrid sg;
     uint32_t level_mask;
-    uint32_t pad[6];
+    uint32_t level_off[PLAN_MAX_LEVELS + 1];   // first counter of every level (copy of PlanLayout::level_off:
+                                               // the sampling kernels index it by lane)
 };
 
 // Host+device view of the workspace (plain offsets; computed identically by every entry point
@@ -87,10 +88,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // 128 bytes apart 25/ns, the chip's ceiling), and the coarse levels have few cells but can
 // hold most Gaussians -- so a level's counters are spread over at least 256 lines (up to one
 // line per counter).  The padding counters stay zero; the scan sums over them unchanged.
-__host__ __device__ inline int level_shift(uint32_t cells) {
-    int sh = 0;
-    while (sh < 5 && (cells << sh) < 8192u) ++sh;
-    return sh;
+__host__ __device__ inline int level_shift(uint32_t cells) {     // cells: a power of two
+    const int sh = 13 - (31 - __builtin_clz(cells | 1u));
+    return sh < 0 ? 0 : sh > 5 ? 5 : sh;
 }
 
 inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
