@@ -17,6 +17,7 @@ cpu_baseline (the reference's dense PyTorch algorithm on the host cores, bounded
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -129,8 +130,13 @@ def main():
     else:
         nx, ny, res = 128, 64, 256
     gs = synthetic.lattice_gaussians(nx, ny, a.kappa, seed=0)
-    # weak scaling: rank r owns rows [r*res, (r+1)*res) of a res x (world*res) grid over [-1,1]^2
-    pts = synthetic.grid_samples(res, res * world, row0=rank * res, rows=res)
+    # weak scaling (the grid shards by blocks of rows, the Gaussians are replicated): the
+    # global grid is the square side x side grid over [-1,1]^2 with ~res*res points per GPU
+    # (side = round(res * sqrt(world)): 1024, 1448, 2048, 2896 for 1, 2, 4, 8 GPUs -- isotropic
+    # spacing at every N); rank r owns rows [r*rows, (r+1)*rows), rows = side // world
+    side = int(round(res * math.sqrt(world)))
+    rows = side // world
+    pts = synthetic.grid_samples(side, side, row0=rank * rows, rows=rows)
     N, M = gs["means"].shape[0], pts.shape[0]
     t = {k: v.float().to(dev) for k, v in gs.items()}
     pts_d = pts.float().to(dev)
@@ -232,8 +238,8 @@ def main():
         "unit": "sample-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded lattice Gaussians, regular sample grid)",
-        "config": {"workload": f"{a.workload}: {N} Gaussians x {res}x{res} grid per GPU, d=2, c=1, "
-                               f"kappa={a.kappa}, orders 0-2", "gaussians": N, "points_per_gpu": M,
+        "config": {"workload": f"{a.workload}: {N} Gaussians x {side}x{side} grid, {rows} rows x {side} points per "
+                               f"GPU, d=2, c=1, kappa={a.kappa}, orders 0-2", "gaussians": N, "points_per_gpu": M,
                    "kappa": a.kappa, "path": "binned" if sampler._plan is not None else "dense", "step": "preprocess + fused forward (orders 0..2)"},
         "roofline": roofline, "fwd_bwd": fwd_bwd,
     }
