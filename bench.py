@@ -59,6 +59,51 @@ def measured_traffic(workload, kappa, binned):
         return None
 
 
+def graph_replay(GaussianSampler, t, pts_d, backend, n):
+    """ms per replay of the captured training step / sampler-only step (fresh leaves and sampler made
+    under the capture stream: autograd remembers the stream a leaf was first used on)."""
+    dev = pts_d.device
+    out = {}
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        req = {k: t[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
+        sampler = GaussianSampler(False, fuse="all", backend=backend)
+        gouts = [None]
+
+        def train_step():
+            sampler.preprocess(req["means"], req["values"], t["covariances"], req["conics"], pts_d)
+            u, ux, uxx = sampler.sample((0, 1, 2))
+            loss = ((u[:, 0] - (uxx[:, 0, 0, 0] + uxx[:, 1, 1, 0])) ** 2).mean() + (ux ** 2).mean()
+            return torch.autograd.grad(loss, list(req.values()))
+
+        def sampler_step():
+            sampler.preprocess(req["means"], req["values"], t["covariances"], req["conics"], pts_d)
+            outs = sampler.sample((0, 1, 2))
+            if gouts[0] is None:
+                gouts[0] = tuple(torch.randn_like(o) for o in outs)
+            return torch.autograd.grad(outs, list(req.values()), grad_outputs=gouts[0])
+
+        for name, fn in (("ms_per_step", train_step), ("sampler_only_ms_per_step", sampler_step)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                keep = fn()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                graph.replay()
+            torch.cuda.synchronize(dev)
+            out[name] = (time.perf_counter() - t0) / n * 1e3
+            del graph, keep
+    torch.cuda.current_stream(dev).wait_stream(side)
+    return out
+
+
 def host_cores():
     """Cores this process may actually use: affinity, capped by the cgroup CPU quota and by the
     GPU box's per-GPU share (16)."""
@@ -230,8 +275,17 @@ def main():
         fwd_bwd = {"ms_per_step": timed(train_step, nb), "sampler_only_ms_per_step": timed(sampler_step, nb),
                    "steps": nb,
                    "what": "ms_per_step: preprocess + fused fwd(0..2) + torch residual loss + fused bwd; "
-                           "sampler_only: the same without the loss (grad_outputs supplied)"
+                           "sampler_only: the same without the loss (grad_outputs supplied); "
+                           "hipgraph_replay (1 GPU): the same two steps captured once and replayed"
                            + ("; parameter grads all-reduced as one [N,6] buffer" if dist is not None else "")}
+
+        if dist is None:
+            # the same two steps captured ONCE into a hipGraph and replayed (no entry point allocates or
+            # synchronises): what a training loop pays when the host is taken out of the way
+            try:
+                fwd_bwd["hipgraph_replay"] = graph_replay(GaussianSampler, t, pts_d, a.backend, nb)
+            except Exception as e:            # report, never lose the bench line over the extra figure
+                fwd_bwd["hipgraph_replay"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     line = {
         "metric": "sample-points/sec (fwd + 1st + 2nd derivatives, fused)", "value": value,
