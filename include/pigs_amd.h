@@ -69,6 +69,21 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
                          void* g_means, void* g_conics, void* g_values, void* stream);
 
 /*
+ * Fused covariance builder -- the caller-side step in front of preprocess():
+ * gaussians.build_covariances(scaling, transform) (gaussians.py:163-193; model_pn.py:499-502,
+ * 538-541, 607-610, 695-698; test_gaussian_sampling.py:36; test_derivatives.py:55-58).  d = 2.
+ *   scaling [N][2] (variances, > 0), transform [N] (raw correlation, squashed by tanh)
+ *   -> covariances [N][3] and conics [N][3], flat (xx, xy, yy); either output may be NULL.
+ * The backward returns the gradients of <g_covariances, cov> + <g_conics, conic> wrt scaling
+ * [N][2] and transform [N]; a NULL incoming gradient reads as zero.
+ */
+int pigs_build_covariances(int dtype, int64_t N, const void* scaling, const void* transform,
+                           void* covariances, void* conics, void* stream);
+int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, const void* transform,
+                                    const void* g_covariances, const void* g_conics,
+                                    void* g_scaling, void* g_transform, void* stream);
+
+/*
  * Binned ("plan") path -- float32, d = 2, c <= 2.  preprocess() builds a plan in a caller-owned
  * device workspace: Gaussians binned by centre into a multi-level cell grid (packed, sorted
  * 32-byte records), sample points sorted into 64-point cells.  The sampling entry points then

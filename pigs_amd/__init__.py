@@ -2,6 +2,7 @@
 
 Public surface:
     GaussianSampler         drop-in for ``diff_gaussian_sampling.GaussianSampler``
+    covariances             fused ``build_covariances`` / ``build_full_covariances`` (gaussians.py:163-193)
     build()                 compile the HIP library in-tree (hipcc, gfx950)
 """
 from .build import build  # noqa: F401

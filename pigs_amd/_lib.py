@@ -28,6 +28,8 @@ SIGNATURES = {
     "pigs_last_hip_error": (ctypes.c_char_p, []),
     "pigs_sample_forward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp]),
     "pigs_sample_backward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp] * 3 + [_vp]),
+    "pigs_build_covariances": (_i, [_i, _i64] + [_vp] * 4 + [_vp]),
+    "pigs_build_covariances_backward": (_i, [_i, _i64] + [_vp] * 6 + [_vp]),
     "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
     "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float] + [_vp] * 4 + [_vp]),
     "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4 + [_vp]),

@@ -67,6 +67,23 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
     return dense_dispatch(true, a, (hipStream_t)stream);
 }
 
+int pigs_build_covariances(int dtype, int64_t N, const void* scaling, const void* transform, void* covariances,
+                           void* conics, void* stream) {
+    if (N < 0) return PIGS_ERR_INVALID;
+    if (N > 0 && (!scaling || !transform || (!covariances && !conics))) return PIGS_ERR_INVALID;
+    return covariances_dispatch(false, dtype, N, scaling, transform, nullptr, nullptr, covariances, conics,
+                                (hipStream_t)stream);
+}
+
+int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, const void* transform,
+                                    const void* g_covariances, const void* g_conics, void* g_scaling,
+                                    void* g_transform, void* stream) {
+    if (N < 0) return PIGS_ERR_INVALID;
+    if (N > 0 && (!scaling || !transform || !g_scaling || !g_transform)) return PIGS_ERR_INVALID;
+    return covariances_dispatch(true, dtype, N, scaling, transform, g_covariances, g_conics, g_scaling, g_transform,
+                                (hipStream_t)stream);
+}
+
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c) { return plan_workspace_bytes(N, M, c); }
 
 int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c,

@@ -18,6 +18,10 @@ struct SampleArgs {
 
 int dense_dispatch(bool backward, const SampleArgs& a, hipStream_t stream);
 
+// covariances.hip
+int covariances_dispatch(bool backward, int dtype, int64_t N, const void* scaling, const void* transform,
+                         const void* a, const void* b, void* o0, void* o1, hipStream_t stream);
+
 // binned.hip
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c);
 int plan_build(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max,

@@ -15,6 +15,7 @@ Runs ONLY in the build container, where the reference is mounted read-only at
 
 Input recipes follow the reference drivers: test_gaussian_sampling.py:13-46,
 test_derivatives.py:13-70, test_1d.py:11-27, gaussians.build_full_covariances (:163-183).
+``ref_build_covariances.npz`` pins the covariance builder itself (gaussians.py:163-193).
 
 Usage:  MPLBACKEND=Agg python tools/gen_golden.py
 """
@@ -187,9 +188,36 @@ def case_random(name, N, M, d, c, seed):
     run_case(name, means, values, full_cov, full_con, samples, seed=seed + 100)
 
 
+def case_build_covariances():
+    """gaussians.build_covariances / build_full_covariances (/root/reference/gaussians.py:163-193):
+    (scaling [N,2] > 0, transform [N,1]) -> flat covariances and conics [N,3], with the gradients of
+    L = sum(cov * r1) + sum(conic * r2) wrt both inputs (torch.autograd through the reference)."""
+    g = torch.Generator().manual_seed(11)
+    N = 257
+    s = torch.exp(torch.randn((N, 2), generator=g, dtype=torch.float64) * 1.5 - 4.0).requires_grad_(True)
+    t = (torch.randn((N, 1), generator=g, dtype=torch.float64) * 1.2).requires_grad_(True)
+    full_cov, full_con = ref.build_full_covariances(s, t)
+    cov, con = ref.flatten_covariances(full_cov, full_con)
+    r1 = torch.rand(cov.shape, generator=g, dtype=torch.float64) * 2 - 1
+    r2 = torch.rand(con.shape, generator=g, dtype=torch.float64) * 2 - 1
+    gs, gt = torch.autograd.grad((cov * r1).sum() + (con * r2).sum(), (s, t))
+    cov32, con32 = ref.build_covariances(s.detach().float(), t.detach().float())
+    path = os.path.join(OUT, "ref_build_covariances.npz")
+    np.savez_compressed(path, scaling=s.detach().numpy(), transform=t.detach().numpy(),
+                        cov=cov.detach().numpy(), conic=con.detach().numpy(),
+                        full_cov=full_cov.detach().numpy(), full_conic=full_con.detach().numpy(),
+                        cov_f32=cov32.numpy(), conic_f32=con32.numpy(),
+                        r_cov=r1.numpy(), r_conic=r2.numpy(), g_scaling=gs.numpy(), g_transform=gt.numpy())
+    print("wrote", path)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-covariances" in sys.argv:      # keeps the other fixtures' bytes untouched
+        case_build_covariances()
+        return
+    case_build_covariances()
     case_gaussian_sampling()
     case_derivatives()
     case_1d()
