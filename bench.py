@@ -84,7 +84,14 @@ def graph_replay(GaussianSampler, t, pts_d, backend, n):
                 gouts[0] = tuple(torch.randn_like(o) for o in outs)
             return torch.autograd.grad(outs, list(req.values()), grad_outputs=gouts[0])
 
-        for name, fn in (("ms_per_step", train_step), ("sampler_only_ms_per_step", sampler_step)):
+        def trace_step():
+            sampler.preprocess(req["means"], req["values"], t["covariances"], req["conics"], pts_d)
+            u, ux, lap = sampler.sample((0, 1, "lap"))
+            loss = ((u - lap) ** 2).mean() + (ux ** 2).mean()
+            return torch.autograd.grad(loss, list(req.values()))
+
+        for name, fn in (("ms_per_step", train_step), ("sampler_only_ms_per_step", sampler_step),
+                         ("trace_residual_ms_per_step", trace_step)):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize(dev)
@@ -301,12 +308,23 @@ def main():
             barrier()
             return (time.perf_counter() - t0) / n * 1e3
 
+        def trace_step():
+            # the same residual through the fused Hessian-trace output (4 floats per point instead of 7,
+            # no slicing of [M,2,2,1] in the loss): extension of the reference API, SURVEY.md 8f-4
+            m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
+            sampler.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
+            u, ux, lap = sampler.sample((0, 1, "lap"))
+            loss = ((u - lap) ** 2).mean() + (ux ** 2).mean()
+            return torch.autograd.grad(loss, list(req.values()))
+
         nb = max(1, min(a.steps, 10))
         fwd_bwd = {"ms_per_step": timed(train_step, nb), "sampler_only_ms_per_step": timed(sampler_step, nb),
-                   "steps": nb,
+                   "trace_residual_ms_per_step": timed(trace_step, nb), "steps": nb,
                    "what": "ms_per_step: preprocess + fused fwd(0..2) + torch residual loss + fused bwd; "
                            "sampler_only: the same without the loss (grad_outputs supplied); "
-                           "hipgraph_replay (1 GPU): the same two steps captured once and replayed"
+                           "trace_residual: the training step with the fused u, grad u, u_xx+u_yy outputs "
+                           "(sample((0, 1, 'lap'))) instead of the full Hessian; "
+                           "hipgraph_replay (1 GPU): the same steps captured once and replayed"
                            + ("; parameter grads all-reduced as one [N,6] buffer" if dist is not None else "")}
 
         if dist is None:

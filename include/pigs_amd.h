@@ -24,8 +24,12 @@
  *   - layouts: means[N][d], conics[N][d(d+1)/2] (upper triangle row-major: d=2 -> xx,xy,yy,
  *     gaussians.py:186-189), values[N][c], samples[M][d];
  *     out0[M][c], out1[M][d][c], out2[M][d][d][c], out3[M][d][d][d][c]  (model_pn.py:650-654).
- *   - orders_mask: bit k set = derivative order k is requested (outputs) / has an incoming
+ *   - orders_mask: bit k (k = 0..3) set = derivative order k is requested (outputs) / has an incoming
  *     gradient (backward).  Pointers of orders outside the mask may be NULL.
+ *     Bit 4 (value 16) = the TRACE of the order-2 output, u_xx + u_yy, as [M][c] -- the Laplacian
+ *     the PDE residuals consume (model_pn.py:614-617) -- written to / read from the out2 / gout2
+ *     slot in place of the full Hessian; bits 2 and 4 exclude each other (PIGS_ERR_INVALID), the
+ *     trace together with order 3 has no fused kernel (PIGS_ERR_UNSUPPORTED: two calls).
  *   - supported: d in {1,2}, c in {1..4}, dtype f32/f64 (binned plan: d=2, f32).
  *   - return value: PIGS_OK or an error code; pigs_status_string() names it.
  */
@@ -39,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 2
+#define PIGS_ABI_VERSION 3
 
 enum pigs_status {
     PIGS_OK = 0,

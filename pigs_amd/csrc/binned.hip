@@ -1010,7 +1010,7 @@ static int plan_forward_c(const PlanView& pv, int mask, float* const* out, hipSt
                            out[3]);                                                                          \
         break;
     switch (mask) {
-        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15)
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
         default: return PIGS_ERR_UNSUPPORTED;
     }
 #undef PIGS_CASE
@@ -1027,18 +1027,12 @@ static int plan_backward_c(const PlanView& pv, int mask, const float* const* g, 
         hipLaunchKernelGGL((binned_backward_kernel<C, MK>), grid, block, 0, stream, pv, g[0], g[1], g[2], g[3]); \
         break;
     switch (mask) {
-        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15)
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
         default: return PIGS_ERR_UNSUPPORTED;
     }
 #undef PIGS_CASE
     hipLaunchKernelGGL((plan_unpermute_kernel<C>), dim3((pv.N + 255) / 256), dim3(256), 0, stream, pv, gm, gc, gv);
     return launch_status();
-}
-
-static int covering_mask_b(int mask) {
-    if (mask == 1 || mask == 2 || mask == 4 || mask == 8) return mask;
-    if ((mask & ~7) == 0) return 7;
-    return 15;
 }
 
 int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask, void* const* out,
@@ -1048,8 +1042,8 @@ int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q
     if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
     const PlanView pv = make_view(p, ws, q_max);
     float* o[4];
-    for (int k = 0; k < 4; ++k) o[k] = (mask >> k & 1) ? (float*)out[k] : nullptr;
-    const int cm = covering_mask_b(mask);
+    for (int k = 0; k < 4; ++k) o[k] = mask_uses_slot(mask, k) ? (float*)out[k] : nullptr;
+    const int cm = covering_mask_of(mask);
     switch (c) {
         case 1: return plan_forward_c<1>(pv, cm, o, stream);
         case 2: return plan_forward_c<2>(pv, cm, o, stream);
@@ -1064,8 +1058,8 @@ int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float 
     if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
     const PlanView pv = make_view(p, ws, q_max);
     const float* g[4];
-    for (int k = 0; k < 4; ++k) g[k] = (mask >> k & 1) ? (const float*)gout[k] : nullptr;
-    const int cm = covering_mask_b(mask);
+    for (int k = 0; k < 4; ++k) g[k] = mask_uses_slot(mask, k) ? (const float*)gout[k] : nullptr;
+    const int cm = covering_mask_of(mask);
     switch (c) {
         case 1: return plan_backward_c<1>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
         case 2: return plan_backward_c<2>(pv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);

@@ -10,7 +10,7 @@ thread_local hipError_t g_last_hip_error = hipSuccess;
 static int check_common(int dtype, int d, int c, int mask, int64_t N, int64_t M, const void* means,
                         const void* conics, const void* values, const void* samples) {
     if (dtype != PIGS_F32 && dtype != PIGS_F64) return PIGS_ERR_UNSUPPORTED;
-    if (d < 1 || c < 1 || N < 0 || M < 0 || mask <= 0 || mask > 15) return PIGS_ERR_INVALID;
+    if (d < 1 || c < 1 || N < 0 || M < 0 || !mask_valid(mask)) return PIGS_ERR_INVALID;
     if (d > 2 || c > 4) return PIGS_ERR_UNSUPPORTED;
     if (N > 0 && (!means || !conics || !values)) return PIGS_ERR_INVALID;
     if (M > 0 && !samples) return PIGS_ERR_INVALID;
@@ -41,11 +41,11 @@ int pigs_sample_forward(int dtype, int d, int c, int orders_mask, int64_t N, int
     if (rc != PIGS_OK) return rc;
     void* outs[4] = {out0, out1, out2, out3};
     for (int k = 0; k < 4; ++k)
-        if ((orders_mask >> k & 1) && M > 0 && !outs[k]) return PIGS_ERR_INVALID;
+        if (mask_uses_slot(orders_mask, k) && M > 0 && !outs[k]) return PIGS_ERR_INVALID;
     SampleArgs a{};
     a.dtype = dtype; a.d = d; a.c = c; a.orders_mask = orders_mask; a.N = N; a.M = M;
     a.means = means; a.conics = conics; a.values = values; a.samples = samples;
-    for (int k = 0; k < 4; ++k) a.out[k] = (orders_mask >> k & 1) ? outs[k] : nullptr;
+    for (int k = 0; k < 4; ++k) a.out[k] = mask_uses_slot(orders_mask, k) ? outs[k] : nullptr;
     return dense_dispatch(false, a, (hipStream_t)stream);
 }
 
@@ -57,12 +57,12 @@ int pigs_sample_backward(int dtype, int d, int c, int orders_mask, int64_t N, in
     if (rc != PIGS_OK) return rc;
     const void* gs[4] = {gout0, gout1, gout2, gout3};
     for (int k = 0; k < 4; ++k)
-        if ((orders_mask >> k & 1) && M > 0 && !gs[k]) return PIGS_ERR_INVALID;
+        if (mask_uses_slot(orders_mask, k) && M > 0 && !gs[k]) return PIGS_ERR_INVALID;
     if (N > 0 && (!g_means || !g_conics || !g_values)) return PIGS_ERR_INVALID;
     SampleArgs a{};
     a.dtype = dtype; a.d = d; a.c = c; a.orders_mask = orders_mask; a.N = N; a.M = M;
     a.means = means; a.conics = conics; a.values = values; a.samples = samples;
-    for (int k = 0; k < 4; ++k) a.gout[k] = (orders_mask >> k & 1) ? gs[k] : nullptr;
+    for (int k = 0; k < 4; ++k) a.gout[k] = mask_uses_slot(orders_mask, k) ? gs[k] : nullptr;
     a.g_means = g_means; a.g_conics = g_conics; a.g_values = g_values;
     return dense_dispatch(true, a, (hipStream_t)stream);
 }
@@ -97,20 +97,20 @@ int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t 
 
 int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
                       int orders_mask, void* out0, void* out1, void* out2, void* out3, void* stream) {
-    if (orders_mask <= 0 || orders_mask > 15) return PIGS_ERR_INVALID;
+    if (!mask_valid(orders_mask)) return PIGS_ERR_INVALID;
     void* outs[4] = {out0, out1, out2, out3};
     for (int k = 0; k < 4; ++k)
-        if ((orders_mask >> k & 1) && !outs[k]) return PIGS_ERR_INVALID;
+        if (mask_uses_slot(orders_mask, k) && !outs[k]) return PIGS_ERR_INVALID;
     return plan_forward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, outs, (hipStream_t)stream);
 }
 
 int pigs_plan_backward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
                        int orders_mask, const void* gout0, const void* gout1, const void* gout2,
                        const void* gout3, void* g_means, void* g_conics, void* g_values, void* stream) {
-    if (orders_mask <= 0 || orders_mask > 15) return PIGS_ERR_INVALID;
+    if (!mask_valid(orders_mask)) return PIGS_ERR_INVALID;
     const void* gs[4] = {gout0, gout1, gout2, gout3};
     for (int k = 0; k < 4; ++k)
-        if ((orders_mask >> k & 1) && !gs[k]) return PIGS_ERR_INVALID;
+        if (mask_uses_slot(orders_mask, k) && !gs[k]) return PIGS_ERR_INVALID;
     if (!g_means || !g_conics || !g_values) return PIGS_ERR_INVALID;
     return plan_backward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, gs, g_means, g_conics, g_values,
                          (hipStream_t)stream);

@@ -249,24 +249,17 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     return launch_status();
 }
 
-// Smallest compiled order mask that covers the request.  Compiled: single orders, 0..2 and 0..3.
-static int covering_mask(int mask) {
-    if (mask == 1 || mask == 2 || mask == 4 || mask == 8) return mask;
-    if ((mask & ~7) == 0) return 7;
-    return 15;
-}
-
 template <typename T, int D, int C>
 static int dispatch_mask(bool backward, const SampleArgs& a, hipStream_t stream) {
     // Orders inside the covering mask that were not requested have null output / gradient
     // pointers: the forward skips their stores, the backward reads their gradients as zero.
-    const int mask = covering_mask(a.orders_mask);
+    const int mask = covering_mask_of(a.orders_mask);
 #define PIGS_CASE(MK)                                                                        \
     case MK:                                                                                 \
         return backward ? launch_dense_backward<T, D, C, MK>(a, stream)                      \
                         : launch_dense_forward<T, D, C, MK>(a, stream);
     switch (mask) {
-        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15)
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
         default: break;
     }
 #undef PIGS_CASE

@@ -32,6 +32,19 @@ int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q
 int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask,
                   const void* const* gout, void* g_means, void* g_conics, void* g_values, hipStream_t stream);
 
+// Order masks: bit k < 4 = derivative order k (pointer slot k); bit 4 (16) = the TRACE of the order-2
+// output (the Laplacian), which takes pointer slot 2 in place of the full Hessian, [M][c].
+inline bool mask_valid(int m) { return m > 0 && m < 32 && !((m & 4) && (m & 16)); }
+inline bool mask_uses_slot(int m, int k) { return (m >> k & 1) || (k == 2 && (m & 16)); }
+// Smallest compiled mask covering the request (compiled: single orders, 0..2, 0..3, the trace alone
+// and orders 0, 1 + trace); 0 = no compiled kernel (trace together with order 3).
+inline int covering_mask_of(int mask) {
+    if (mask & 16) return mask == 16 ? 16 : (mask & ~19) == 0 ? 19 : 0;
+    if (mask == 1 || mask == 2 || mask == 4 || mask == 8) return mask;
+    if ((mask & ~7) == 0) return 7;
+    return 15;
+}
+
 // The HIP "last error" is sticky per thread and the host process (PyTorch) makes its own HIP
 // calls: clear it before a launch, read it after.
 extern thread_local hipError_t g_last_hip_error;      // capi.hip; reported by pigs_last_hip_error()

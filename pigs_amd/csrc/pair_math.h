@@ -16,6 +16,9 @@
 namespace pigs {
 
 constexpr int ORD0 = 1, ORD1 = 2, ORD2 = 4, ORD3 = 8;
+// trace of the Hessian (the Laplacian the PDE residuals consume, model_pn.py:614-617) instead of
+// the full Hessian: one value per channel in the order-2 slot; never together with ORD2
+constexpr int ORD2T = 16;
 
 template <int D> struct Sym {
     static constexpr int NF = D * (D + 1) / 2;            // distinct 2nd-order components
@@ -37,7 +40,7 @@ template <int D, int C, int MASK> struct FwdLayout {
     static constexpr int O0 = 0;
     static constexpr int O1 = O0 + ((MASK & ORD0) ? C : 0);
     static constexpr int O2 = O1 + ((MASK & ORD1) ? D * C : 0);
-    static constexpr int O3 = O2 + ((MASK & ORD2) ? Sym<D>::NF * C : 0);
+    static constexpr int O3 = O2 + ((MASK & ORD2) ? Sym<D>::NF * C : (MASK & ORD2T) ? C : 0);
     static constexpr int N = O3 + ((MASK & ORD3) ? Sym<D>::N3 * C : 0);
 };
 
@@ -69,14 +72,14 @@ __device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, 
     if constexpr (D == 1) {
         const T p = pr.p[0];
         T t2 = 0, t3 = 0;
-        if constexpr ((MASK & (ORD2 | ORD3)) != 0) t2 = fma_<T>(p, p, -con[0]);
+        if constexpr ((MASK & (ORD2 | ORD2T | ORD3)) != 0) t2 = fma_<T>(p, p, -con[0]);
         if constexpr ((MASK & ORD3) != 0) t3 = p * (T(2) * con[0] - t2);
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
             const T w = v[ch] * pr.g;
             if constexpr ((MASK & ORD0) != 0) acc[L::O0 + ch] += w;
             if constexpr ((MASK & ORD1) != 0) acc[L::O1 + ch] = fma_<T>(p, w, acc[L::O1 + ch]);
-            if constexpr ((MASK & ORD2) != 0) acc[L::O2 + ch] = fma_<T>(t2, w, acc[L::O2 + ch]);
+            if constexpr ((MASK & (ORD2 | ORD2T)) != 0) acc[L::O2 + ch] = fma_<T>(t2, w, acc[L::O2 + ch]);   // d = 1: trace = u_xx
             if constexpr ((MASK & ORD3) != 0) acc[L::O3 + ch] = fma_<T>(t3, w, acc[L::O3 + ch]);
         }
     } else {
@@ -87,6 +90,11 @@ __device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, 
             tyy = fma_<T>(py, py, -con[2]);
         }
         if constexpr ((MASK & ORD2) != 0) txy = fma_<T>(px, py, -con[1]);
+        T ttr = 0;      // |p|^2 - tr C
+        if constexpr ((MASK & ORD2T) != 0) {
+            if constexpr ((MASK & ORD3) != 0) ttr = txx + tyy;
+            else ttr = fma_<T>(px, px, fma_<T>(py, py, -(con[0] + con[2])));
+        }
         if constexpr ((MASK & ORD3) != 0) {
             // C_ij p_k + C_ik p_j + C_jk p_i - p_i p_j p_k, written through t_ij = p_i p_j - C_ij
             const T b2 = T(2) * con[1];
@@ -108,6 +116,7 @@ __device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, 
                 acc[L::O2 + 1 * C + ch] = fma_<T>(txy, w, acc[L::O2 + 1 * C + ch]);
                 acc[L::O2 + 2 * C + ch] = fma_<T>(tyy, w, acc[L::O2 + 2 * C + ch]);
             }
+            if constexpr ((MASK & ORD2T) != 0) acc[L::O2 + ch] = fma_<T>(ttr, w, acc[L::O2 + ch]);
             if constexpr ((MASK & ORD3) != 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[L::O3 + k * C + ch] = fma_<T>(t3[k], w, acc[L::O3 + k * C + ch]);
@@ -146,6 +155,12 @@ __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch)
                         o2[((m * D + i) * D + j) * C + ch] = acc[L::O2 + (i + j) * C + ch];  // D<=2: sym index = i+j
+        }
+    }
+    if constexpr ((MASK & ORD2T) != 0) {      // trace: out2 is [M][c]
+        if (o2) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) o2[m * C + ch] = acc[L::O2 + ch];
         }
     }
     if constexpr ((MASK & ORD3) != 0) {
@@ -198,6 +213,11 @@ template <typename T, int D, int C, int MASK> struct Gsym {
 #pragma unroll
                     for (int j = 0; j < D; ++j) g2[i + j][ch] += G2 ? G2[((m * D + i) * D + j) * C + ch] : T(0);
             }
+            if constexpr ((MASK & ORD2T) != 0) {   // gradient of the trace = gl * identity
+                const T gl = G2 ? G2[m * C + ch] : T(0);
+#pragma unroll
+                for (int k = 0; k < Sym<D>::NF; ++k) g2[k][ch] = (k == 0 || k == Sym<D>::NF - 1) ? gl : T(0);
+            }
             if constexpr ((MASK & ORD3) != 0) {
 #pragma unroll
                 for (int k = 0; k < Sym<D>::N3; ++k) g3[k][ch] = 0;
@@ -238,7 +258,7 @@ __device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, 
             T F = 0, dF = 0, eF = 0;
             if constexpr ((MASK & ORD0) != 0) F += G.g0[ch];
             if constexpr ((MASK & ORD1) != 0) { F = fma_<T>(-G.g1[0][ch], p, F); dF -= G.g1[0][ch]; }
-            if constexpr ((MASK & ORD2) != 0) {
+            if constexpr ((MASK & (ORD2 | ORD2T)) != 0) {
                 F = fma_<T>(G.g2[0][ch], t2, F);
                 dF = fma_<T>(T(2) * G.g2[0][ch], p, dF);
                 eF -= G.g2[0][ch];
@@ -270,7 +290,7 @@ __device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, 
                 dFx -= G.g1[0][ch];
                 dFy -= G.g1[1][ch];
             }
-            if constexpr ((MASK & ORD2) != 0) {
+            if constexpr ((MASK & (ORD2 | ORD2T)) != 0) {
                 const T hxx = G.g2[0][ch], hxy = G.g2[1][ch], hyy = G.g2[2][ch];
                 F = fma_<T>(hxx, txx, F);
                 F = fma_<T>(hxy, txy, F);

@@ -30,8 +30,11 @@ _ORDER_NAMES = ("sample_gaussians", "sample_gaussians_derivative", "sample_gauss
 _DTYPES = {torch.float32: _lib.PIGS_F32, torch.float64: _lib.PIGS_F64}
 
 
+TRACE = 4       # order index of the Hessian's trace (mask bit 16); it travels in pointer slot 2
+
+
 def _out_shape(order, M, d, c):
-    return (M,) + (d,) * order + (c,)
+    return (M, c) if order == TRACE else (M,) + (d,) * order + (c,)
 
 
 def _ptr(t):
@@ -62,7 +65,12 @@ _WORKSPACE_BYTES = {}
 
 
 def _mask_orders(mask):
-    return [k for k in range(4) if mask >> k & 1]
+    return [k for k in range(5) if mask >> k & 1]
+
+
+def _slot2(ts):
+    """Pointer slot 2 of the C ABI: the full Hessian, or its trace when that is what the mask asks for."""
+    return ts[2] if ts[2] is not None else ts[TRACE]
 
 
 class Plan:
@@ -96,32 +104,33 @@ class Plan:
 
 def forward_raw(means, values, conics, samples, mask, plan=None):
     """Launch the forward for the orders in ``mask`` on contiguous device tensors (through the
-    plan when given, else dense).  Returns a list of 4 entries (tensor or None)."""
+    plan when given, else dense).  Returns a list of 5 entries (tensor or None): orders 0..3 and the
+    Hessian's trace."""
     lib = _lib.load()
     N, d = means.shape
     c = values.shape[1]
     M = samples.shape[0]
-    outs = [None] * 4
+    outs = [None] * 5
     for k in _mask_orders(mask):
         outs[k] = torch.empty(_out_shape(k, M, d, c), dtype=means.dtype, device=means.device)
     if M > 0:
         with _on_device(means.device):
             if plan is not None:
                 rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
-                                           _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]),
+                                           _ptr(outs[0]), _ptr(outs[1]), _ptr(_slot2(outs)), _ptr(outs[3]),
                                            _stream(means.device))
                 _lib.check(rc, "pigs_plan_forward")
             else:
                 rc = lib.pigs_sample_forward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
                                              _ptr(values), _ptr(samples), _ptr(outs[0]), _ptr(outs[1]),
-                                             _ptr(outs[2]), _ptr(outs[3]), _stream(means.device))
+                                             _ptr(_slot2(outs)), _ptr(outs[3]), _stream(means.device))
                 _lib.check(rc, "pigs_sample_forward")
     return outs
 
 
 def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
-    """Launch the backward; ``gouts`` has 4 entries (contiguous tensor or None), ``mask`` marks the
-    non-None ones.  Returns (g_means, g_values, g_conics)."""
+    """Launch the backward; ``gouts`` has 5 entries (contiguous tensor or None: orders 0..3 and the
+    trace), ``mask`` marks the non-None ones.  Returns (g_means, g_values, g_conics)."""
     lib = _lib.load()
     N, d = means.shape
     c = values.shape[1]
@@ -133,14 +142,14 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
         with _on_device(means.device):
             if plan is not None and M > 0:
                 rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
-                                            _ptr(gouts[0]), _ptr(gouts[1]), _ptr(gouts[2]),
+                                            _ptr(gouts[0]), _ptr(gouts[1]), _ptr(_slot2(gouts)),
                                             _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics), _ptr(g_values),
                                             _stream(means.device))
                 _lib.check(rc, "pigs_plan_backward")
             else:
                 rc = lib.pigs_sample_backward(_DTYPES[means.dtype], d, c, mask, N, M, _ptr(means), _ptr(conics),
                                               _ptr(values), _ptr(samples), _ptr(gouts[0]), _ptr(gouts[1]),
-                                              _ptr(gouts[2]), _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics),
+                                              _ptr(_slot2(gouts)), _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics),
                                               _ptr(g_values), _stream(means.device))
                 _lib.check(rc, "pigs_sample_backward")
     return g_means, g_values, g_conics
@@ -166,7 +175,7 @@ class _SampleFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grad_outputs):
         means, values, conics, samples = ctx.saved_tensors
-        gouts = [None] * 4
+        gouts = [None] * 5
         mask = 0
         for k, g in zip(_mask_orders(ctx.mask), grad_outputs):
             if g is not None:
@@ -304,13 +313,23 @@ class GaussianSampler:
 
     def sample(self, orders=(0, 1, 2)):
         """Fused entry point: one launch for all ``orders`` (extension of the reference API).
-        Returns a tuple of outputs in the order given."""
-        orders = tuple(int(o) for o in orders)
-        if any(o < 0 or o > 3 for o in orders):
-            raise ValueError("orders must be in 0..3")
-        mask = sum(1 << o for o in set(orders) if o not in self._cache)
+        ``orders`` holds derivative orders 0..3 and / or ``"lap"`` -- the trace of the Hessian
+        u_xx + u_yy as [M, c], what the PDE residuals consume (model_pn.py:614-617) -- e.g.
+        ``sample((0, 1, "lap"))``.  Returns a tuple of outputs in the order given."""
+        orders = tuple(TRACE if o == "lap" else int(o) for o in orders)
+        if any(o < 0 or o > TRACE for o in orders):
+            raise ValueError('orders must be in 0..3 or "lap"')
+        want = set(o for o in orders if o not in self._cache)
+        if TRACE in want and (2 in want or 2 in self._cache):
+            want.discard(TRACE)                    # the Hessian is (being) computed: take its diagonal
+        if TRACE in want and 3 in want:            # no fused kernel for trace + order 3: two launches
+            self._compute(1 << 3)
+            want.discard(3)
+        mask = sum(1 << o for o in want)
         if mask:
             self._compute(mask)
+        if TRACE in orders and TRACE not in self._cache:
+            self._cache[TRACE] = self._cache[2].diagonal(dim1=1, dim2=2).sum(-1)
         return tuple(self._cache[o] for o in orders)
 
     def sample_gaussians(self):
@@ -324,6 +343,11 @@ class GaussianSampler:
     def sample_gaussians_laplacian(self):
         """full Hessian [M, d, d, c] (the reference's name is a misnomer: model_pn.py:614,652)"""
         return self._get(2)
+
+    def sample_gaussians_laplacian_trace(self):
+        """u_xx + u_yy [M, c]: the trace of the Hessian in its own launch (extension; 4 floats per
+        point with u and grad u instead of 7, and no slicing of [M, d, d, c] in the residual)"""
+        return self.sample(("lap",))[0]
 
     def sample_gaussians_third_derivative(self):
         """third derivatives [M, d, d, d, c]"""
