@@ -13,7 +13,7 @@
 // the points' original indices) plus record reads that mostly hit L2.
 //
 // Build-time knobs (defaults measured on MI355X): PIGS_FWD_WAVES, PIGS_FWD_UNROLL,
-// PIGS_FWD_BLOCK_WAVES, PIGS_TRAV_STEPS, PIGS_BWD_WAVES, PIGS_BWD_GROUP; PIGS_STAMPS=1 builds the
+// PIGS_FWD_BLOCK_WAVES, PIGS_TRAV_STEPS, PIGS_BWD_WAVES; PIGS_STAMPS=1 builds the
 // diagnostic variant read by tools/stamps.py.
 #include "pair_math.h"
 #include "plan.h"
@@ -33,9 +33,6 @@
 #endif
 #ifndef PIGS_BWD_WAVES
 #define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to
-#endif
-#ifndef PIGS_BWD_GROUP
-#define PIGS_BWD_GROUP 4      // records reduced together by the backward's butterfly (4 or 8)
 #endif
 #ifndef PIGS_TRAV_STEPS
 #define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
@@ -457,24 +454,31 @@ struct WaveLdsT {
 };
 using WaveLds = WaveLdsT<QCAP>;
 
-// Wave-wide min / max with the DPP modifier fused into the min (hipcc emits v_mov_dpp + a
-// canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  "s_nop 1"
-// covers the VALU-write -> DPP-read wait states inside the asm.  Result broadcast from lane 63.
-#define PIGS_DPP_REDUCE(OP)                                                                      \
-    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"            \
-    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"            \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                     \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                   \
-    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                   \
-    "s_nop 1"
-__device__ __forceinline__ float wave_min_dpp(float v) {
-    asm volatile(PIGS_DPP_REDUCE("v_min_f32_dpp") : "+v"(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    asm volatile(PIGS_DPP_REDUCE("v_max_f32_dpp") : "+v"(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+// Wave-wide bounding box {min x, max x, min y, max y} with the DPP modifier fused into the min / max
+// (hipcc emits v_mov_dpp + a canonicalising v_max + v_min per step from the builtin form: 4x the
+// instructions).  The four reductions are independent chains and are interleaved step by step, so
+// the two wait states a DPP read needs after the VALU write of its source are filled by the other
+// three chains: one s_nop at the head instead of one per step (an s_nop costs an issue slot like a
+// VALU instruction).  Results broadcast from lane 63.
+#define PIGS_BOX_STEP(MOD)                                \
+    "v_min_f32_dpp %0, %0, %0 " MOD " bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %1, %1, %1 " MOD " bank_mask:0xf\n\t" \
+    "v_min_f32_dpp %2, %2, %2 " MOD " bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %3, %3, %3 " MOD " bank_mask:0xf\n\t"
+__device__ __forceinline__ void wave_box_dpp(float& x0, float& x1, float& y0, float& y1) {
+    asm volatile("s_nop 1\n\t"
+                 PIGS_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
+                 PIGS_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
+                 PIGS_BOX_STEP("row_half_mirror row_mask:0xf")
+                 PIGS_BOX_STEP("row_mirror row_mask:0xf")
+                 PIGS_BOX_STEP("row_bcast:15 row_mask:0xa")
+                 PIGS_BOX_STEP("row_bcast:31 row_mask:0xc")
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+    x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x0), 63));
+    x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x1), 63));
+    y0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y0), 63));
+    y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), 63));
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -688,8 +692,8 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, (fwd_waves<C, MASK>())) 
         SPoint sp = {0.f, 0.f, 0u};
         if (valid) sp = pv.spts[base + lane];
         float s[2] = {sp.x, sp.y};
-        const float bx0 = wave_min_dpp(valid ? s[0] : INF), bx1 = wave_max_dpp(valid ? s[0] : -INF);
-        const float by0 = wave_min_dpp(valid ? s[1] : INF), by1 = wave_max_dpp(valid ? s[1] : -INF);
+        float bx0 = valid ? s[0] : INF, bx1 = valid ? s[0] : -INF, by0 = valid ? s[1] : INF, by1 = valid ? s[1] : -INF;
+        wave_box_dpp(bx0, bx1, by0, by1);
         if (!valid) { s[0] = bx0; s[1] = by0; }
 
         float acc[L::N];
@@ -746,24 +750,64 @@ struct WaveLdsBwd {
 
 // hipcc (ROCm 7.2) mis-lowers __builtin_amdgcn_permlane{32,16}_swap when both results feed one
 // add (it emits v_add v, v, v with the FIRST result twice), so the swaps are inline asm.  The
-// s_nop covers the VALU-write -> permlane-swap-read wait states the compiler would insert.
-__device__ __forceinline__ float swap32_add(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;     // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+// butterfly works on GROUPS of three or four values at a time: their swaps and DPP steps are
+// independent chains, interleaved so that one s_nop at the head of a block covers the VALU-write
+// -> swap / DPP-read wait states that a nop per instruction covered before (58 -> 9 nops per four
+// records; each costs an issue slot).
+//   swap32: lanes 0-31 <- a[l] , a[l+32] ; lanes 32-63 <- b[l-32] , b[l]   (the pair is then added)
+//   swap16: rows 0,2 <- a[row] , a[row+1] ; rows 1,3 <- b[row-1] , b[row]
+template <int G>
+__device__ __forceinline__ void swap32_add_group(float* x, float* a, float* b) {     // x[k] = swap32_add(a[k], b[k])
+    static_assert(G == 3 || G == 4, "groups of three or four");
+    if constexpr (G == 3)
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                     "v_permlane32_swap_b32 %4, %5"
+                     : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]));
+    else
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                     "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7"
+                     : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]));
+#pragma unroll
+    for (int k = 0; k < G; ++k) x[k] = a[k] + b[k];
 }
-__device__ __forceinline__ float swap16_add(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;     // rows 0,2: a[row] + a[row+1]; rows 1,3: b[row-1] + b[row]
+template <int G>
+__device__ __forceinline__ void swap16_add_group(float* y, float* a, float* b) {
+    if constexpr (G == 3)
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                     "v_permlane16_swap_b32 %4, %5"
+                     : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]));
+    else
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                     "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+                     : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]));
+#pragma unroll
+    for (int k = 0; k < G; ++k) y[k] = a[k] + b[k];
 }
-__device__ __forceinline__ float row_sum(float v) {      // sum over the 16 lanes of a row, in every lane
-    asm volatile(
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return v;
+// sum over the 16 lanes of a row, in every lane, for G values at once
+#define PIGS_ROW3(MOD)                                                   \
+    "v_add_f32_dpp %0, %0, %0 " MOD " row_mask:0xf bank_mask:0xf\n\t"   \
+    "v_add_f32_dpp %1, %1, %1 " MOD " row_mask:0xf bank_mask:0xf\n\t"   \
+    "v_add_f32_dpp %2, %2, %2 " MOD " row_mask:0xf bank_mask:0xf\n\t"
+#define PIGS_ROW4(MOD) PIGS_ROW3(MOD) "v_add_f32_dpp %3, %3, %3 " MOD " row_mask:0xf bank_mask:0xf\n\t"
+template <int G>
+__device__ __forceinline__ void row_sum_group(float* y) {
+    if constexpr (G == 3)
+        asm volatile("s_nop 1\n\t" PIGS_ROW3("quad_perm:[1,0,3,2]") PIGS_ROW3("quad_perm:[2,3,0,1]")
+                     PIGS_ROW3("row_half_mirror") PIGS_ROW3("row_mirror") "s_nop 1"
+                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]));
+    else
+        asm volatile("s_nop 1\n\t" PIGS_ROW4("quad_perm:[1,0,3,2]") PIGS_ROW4("quad_perm:[2,3,0,1]")
+                     PIGS_ROW4("row_half_mirror") PIGS_ROW4("row_mirror") "s_nop 1"
+                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+// y[k] = sum over the 64 lanes of part[r][k], delivered in row r (r = 0..3), for values k0 .. k0+G-1
+template <int G, int NV>
+__device__ __forceinline__ void butterfly_group(float (*part)[NV], int k0, float* y) {
+    float x0[G], x1[G];
+    swap32_add_group<G>(x0, &part[0][k0], &part[2][k0]);     // lanes 0-31 <- records 0 / 1, lanes 32-63 <- 2 / 3
+    swap32_add_group<G>(x1, &part[1][k0], &part[3][k0]);
+    swap16_add_group<G>(y + k0, x0, x1);                     // rows {0,2} <- even, rows {1,3} <- odd records
+    row_sum_group<G>(y + k0);
 }
 
 template <int C, int MASK>
@@ -777,37 +821,7 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
         lds.t.queue[n + lane][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int row = lane >> 4, col = lane & 15;
-#if PIGS_BWD_GROUP == 8
-    for (int k0 = 0; k0 < n; k0 += 8) {
-        float part[8][NV];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const Rec r = make_rec(lds.t.queue[k0 + u][0], lds.t.queue[k0 + u][1]);
-#pragma unroll
-            for (int k = 0; k < NV; ++k) part[u][k] = 0.f;
-            bwd_accumulate<float, 2, C, MASK>(part[u], s, r.mu, r.con, r.v, G);
-        }
-        // lanes 0-31 <- records u, lanes 32-63 <- u+4 ; then rows {0,2} <- u, rows {1,3} <- u+2
-        float y0[NV], y1[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const float x0 = swap32_add(part[0][k], part[4][k]);
-            const float x1 = swap32_add(part[1][k], part[5][k]);
-            const float x2 = swap32_add(part[2][k], part[6][k]);
-            const float x3 = swap32_add(part[3][k], part[7][k]);
-            y0[k] = row_sum(swap16_add(x0, x2));     // row r holds record 2r
-            y1[k] = row_sum(swap16_add(x1, x3));     // row r holds record 2r + 1
-        }
-        if (col == 0) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                lds.sums[k0 + 2 * row][k] = y0[k];
-                lds.sums[k0 + 2 * row + 1][k] = y1[k];
-            }
-        }
-    }
-#else
-    // four records per round: the same 2.5 NV instructions per record as eight, half the registers
+    // four records per round: row 0 = record 0, row 1 = record 1, row 2 = record 2, row 3 = record 3
     for (int k0 = 0; k0 < n; k0 += 4) {
         float part[4][NV];
 #pragma unroll
@@ -817,21 +831,15 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
             for (int k = 0; k < NV; ++k) part[u][k] = 0.f;
             bwd_accumulate<float, 2, C, MASK>(part[u], s, r.mu, r.con, r.v, G);
         }
-        // lanes 0-31 <- records 0 / 1, lanes 32-63 <- 2 / 3 ; then rows {0,2} <- even, rows {1,3} <- odd:
-        // row 0 = record 0, row 1 = record 1, row 2 = record 2, row 3 = record 3
         float y[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const float x0 = swap32_add(part[0][k], part[2][k]);
-            const float x1 = swap32_add(part[1][k], part[3][k]);
-            y[k] = row_sum(swap16_add(x0, x1));
-        }
+        butterfly_group<3, NV>(part, 0, y);
+        if constexpr (NV == 6) butterfly_group<3, NV>(part, 3, y);
+        else butterfly_group<4, NV>(part, 3, y);
         if (col == 0) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) lds.sums[k0 + row][k] = y[k];
         }
     }
-#endif
     for (int q0 = 0; q0 < n; q0 += 64) {
         const int slot = q0 + lane;
         if (slot < n) {
@@ -867,8 +875,8 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void binned_backward_k
         SPoint sp = {0.f, 0.f, 0u};
         if (valid) sp = pv.spts[base + lane];
         float s[2] = {sp.x, sp.y};
-        const float bx0 = wave_min_dpp(valid ? s[0] : INF), bx1 = wave_max_dpp(valid ? s[0] : -INF);
-        const float by0 = wave_min_dpp(valid ? s[1] : INF), by1 = wave_max_dpp(valid ? s[1] : -INF);
+        float bx0 = valid ? s[0] : INF, bx1 = valid ? s[0] : -INF, by0 = valid ? s[1] : INF, by1 = valid ? s[1] : -INF;
+        wave_box_dpp(bx0, bx1, by0, by1);
         if (!valid) { s[0] = bx0; s[1] = by0; }
 
         Gsym<float, 2, C, MASK> G;
