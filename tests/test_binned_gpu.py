@@ -218,3 +218,44 @@ def test_config3_65k_x_1024sq_forward(Sampler, kappa):
         s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts[sub].contiguous())
         v = s.sample_gaussians_laplacian()
     assert float((v - uxx[sub]).abs().max() / uxx.abs().max()) < 2e-6
+
+
+def test_config3_65k_x_1024sq_backward(Sampler):
+    """BASELINE.json configs[2] at full size, backward: (i) a loss supported on 4096 sampled points
+    against the oracle's backward on those points; (ii) with gradients on ALL 1M points, the binned
+    backward against the dense HIP backward (no cut-off, no sort), and linearity in the incoming
+    gradients -- size-independent properties where the oracle would take hours."""
+    from pigs_amd import synthetic
+    gs, pts = synthetic.CONFIGS["c3"](0.5)
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    for k in ("means", "values", "conics"):
+        t[k].requires_grad_(True)
+    pts = pts.float().cuda()
+    params = (t["means"], t["values"], t["conics"])
+    s = Sampler(False, fuse="all", backend="binned")
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+    outs = s.sample((0, 1, 2))
+    # (i) oracle on a subsample-supported loss
+    idx = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(8))[:4096].cuda()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    rs = [torch.rand((4096,) + tuple(o.shape[1:]), generator=g) * 2 - 1 for o in outs]
+    loss = sum((o[idx] * r.cuda()).sum() for o, r in zip(outs, rs))
+    gm, gv, gc = torch.autograd.grad(loss, params, retain_graph=True)
+    args = [t[k].detach().cpu().double().numpy() for k in ("means", "conics", "values")]
+    em, ec, ev = c_oracle.backward(*args, pts[idx].cpu().double().numpy(),
+                                   {o: r.double().numpy() for o, r in enumerate(rs)})
+    assert rel(gm, em) < TOL and rel(gv, ev) < TOL and rel(gc, ec) < TOL
+    # (ii) whole grid: binned == dense HIP, and linearity
+    full = [torch.rand(o.shape, generator=g).cuda() * 2 - 1 for o in outs]
+    half = [torch.rand(o.shape, generator=g).cuda() * 2 - 1 for o in outs]
+    b1 = torch.autograd.grad(outs, params, grad_outputs=full, retain_graph=True)
+    b2 = torch.autograd.grad(outs, params, grad_outputs=half, retain_graph=True)
+    b12 = torch.autograd.grad(outs, params, grad_outputs=[a + b for a, b in zip(full, half)])
+    sd = Sampler(False, fuse="all", backend="dense")
+    sd.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+    d1 = torch.autograd.grad(sd.sample((0, 1, 2)), params, grad_outputs=full)
+    for a, b, ab, d in zip(b1, b2, b12, d1):
+        scale = float(d.abs().max())
+        assert torch.isfinite(a).all()
+        assert float((a - d).abs().max()) / scale < TOL          # fp32 sums over 1M points, different orders
+        assert float((a + b - ab).abs().max()) / scale < TOL
