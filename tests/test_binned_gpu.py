@@ -259,3 +259,42 @@ def test_config3_65k_x_1024sq_backward(Sampler):
         assert torch.isfinite(a).all()
         assert float((a - d).abs().max()) / scale < TOL          # fp32 sums over 1M points, different orders
         assert float((a + b - ab).abs().max()) / scale < TOL
+
+
+def test_config4_shard_of_4096sq_grid(Sampler):
+    """BASELINE.json configs[3]: one GPU's share of 65k Gaussians x 4096^2 points sharded over 8 GPUs
+    (512 rows x 4096 = 2M points).  Forward against the oracle on sampled points; and the property
+    the multi-GPU backward rests on: outputs of sub-shards concatenate, and their
+    parameter gradients ADD up to the shard's -- what the all-reduce computes across GPUs."""
+    from pigs_amd import synthetic
+    gs = synthetic.lattice_gaussians(256, 256, 0.5, seed=0)
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    for k in ("means", "values", "conics"):
+        t[k].requires_grad_(True)
+    params = (t["means"], t["values"], t["conics"])
+    rank, world, res = 3, 8, 4096
+    rows = res // world
+    pts = synthetic.grid_samples(res, res, row0=rank * rows, rows=rows).float().cuda()
+    assert pts.shape[0] == 2 * 1024 * 1024
+    s = Sampler(False, fuse="all")
+    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+    assert s._plan is not None
+    outs = s.sample((0, 1, 2))
+    idx = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(1))[:2048].cuda()
+    args = [t[k].detach().cpu().double().numpy() for k in ("means", "conics", "values")]
+    exp = c_oracle.forward(*args, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
+    for o, out in enumerate(outs):
+        assert rel(out[idx], exp[o]) < TOL, o
+    g = torch.Generator(device="cpu").manual_seed(2)
+    gouts = [torch.rand(o.shape, generator=g).cuda() * 2 - 1 for o in outs]
+    whole = torch.autograd.grad(outs, params, grad_outputs=gouts)
+    parts, half = [], pts.shape[0] // 2
+    for lo in (0, half):
+        sub = Sampler(False, fuse="all")
+        sub.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts[lo:lo + half])
+        o = sub.sample((0, 1, 2))
+        for a, b in zip(o, outs):
+            assert float((a - b[lo:lo + half]).abs().max()) <= 2e-6 * float(b.abs().max())
+        parts.append(torch.autograd.grad(o, params, grad_outputs=[x[lo:lo + half] for x in gouts]))
+    for w, a, b in zip(whole, parts[0], parts[1]):
+        assert float((a + b - w).abs().max()) / float(w.abs().max()) < TOL
