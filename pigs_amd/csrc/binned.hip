@@ -735,8 +735,8 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, (fwd_waves<C, MASK>())) 
 // ------------------------------------------------------------------------------------------
 // Backward: same cell / traversal / LDS queue as the forward.  Every (wave, Gaussian) row yields
 // NV = 5 + c per-lane contributions that must be summed over the 64 points.  Rows are processed
-// eight at a time and reduced by a transposing butterfly (v_permlane32_swap, v_permlane16_swap,
-// then 4 DPP steps inside a row): 2.5 NV instructions per Gaussian instead of 6 NV for eight
+// four at a time and reduced by a transposing butterfly (v_permlane32_swap, v_permlane16_swap,
+// then 4 DPP steps inside a row): 2.5 NV instructions per Gaussian instead of 6 NV for four
 // separate wave reductions.  The sums are parked in LDS by queue slot and flushed with one atomic
 // per lane and value into gacc[k][j] (queue order follows the sorted order, so consecutive lanes
 // hit near-consecutive addresses); plan_unpermute_kernel writes the caller's layout.
