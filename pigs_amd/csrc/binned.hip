@@ -667,7 +667,7 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
 template <int C, int MASK>
 constexpr int fwd_waves() {
     constexpr int n = FwdLayout<2, C, MASK>::N;
-    return n > 12 ? 4 : (n > 10 || (C == 1 && MASK == 2)) ? 5 : PIGS_FWD_WAVES;   // <1,2>: 5 spilled VGPRs at 80
+    return n > 12 ? 4 : (n > 10 || (n >= 8 && (MASK & ORD3)) || (C == 1 && MASK == 2)) ? 5 : PIGS_FWD_WAVES;
 }
 template <int C, int MASK>
 __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, (fwd_waves<C, MASK>())) void binned_forward_kernel(
@@ -687,10 +687,12 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, (fwd_waves<C, MASK>())) 
 #if PIGS_STAMPS
     const unsigned long long T0 = stamp();
 #endif
-    for (uint32_t base = sbeg; base < send; base += 64) {
-        const bool valid = base + lane < send;
+    if (sbeg >= send) return;
+    if (send - sbeg <= 64) {
+        // ---- the usual cell: one pass, accumulators live in registers across queue flushes ----
+        const bool valid = sbeg + lane < send;
         SPoint sp = {0.f, 0.f, 0u};
-        if (valid) sp = pv.spts[base + lane];
+        if (valid) sp = pv.spts[sbeg + lane];
         float s[2] = {sp.x, sp.y};
         float bx0 = valid ? s[0] : INF, bx1 = valid ? s[0] : -INF, by0 = valid ? s[1] : INF, by1 = valid ? s[1] : -INF;
         wave_box_dpp(bx0, bx1, by0, by1);
@@ -729,7 +731,47 @@ __global__ __launch_bounds__(64 * PIGS_FWD_BLOCK_WAVES, (fwd_waves<C, MASK>())) 
             g_stamps[cell][4] = T4; g_stamps[cell][5] = (unsigned long long)qn;
         }
 #endif
+        return;
     }
+    // ---- a cell holding more than 64 points (Poisson occupancy, anisotropic grids, clusters): ONE
+    // traversal against the box of all its points; every queue flush is evaluated for each 64-point
+    // chunk in turn, the chunk's partial sums parked in its output rows between flushes ----
+    float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
+    for (uint32_t base = sbeg; base < send; base += 64) {
+        if (base + lane < send) {
+            const SPoint q = pv.spts[base + lane];
+            bx0 = fminf(bx0, q.x); bx1 = fmaxf(bx1, q.x);
+            by0 = fminf(by0, q.y); by1 = fmaxf(by1, q.y);
+        }
+    }
+    wave_box_dpp(bx0, bx1, by0, by1);
+    int qn = 0;
+    bool first = true;
+    auto flush = [&]() {
+        for (uint32_t base = sbeg; base < send; base += 64) {
+            const bool valid = base + lane < send;
+            SPoint sp = {bx0, by0, 0u};
+            if (valid) sp = pv.spts[base + lane];
+            const float s[2] = {sp.x, sp.y};
+            float acc[L::N];
+#pragma unroll
+            for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
+            if (!first && valid) fwd_load<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+            evaluate_queue<C, MASK>(acc, s, lds.queue, qn, lane);
+            if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+        }
+        first = false;
+        qn = 0;
+    };
+    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds,
+             [&](const float4 A, const float4 B, uint64_t mask, uint32_t) {
+        const int cnt = __builtin_popcountll(mask);
+        if (qn + cnt > QCAP) flush();
+        const int slot = qn + lanes_below(mask);
+        if (mask >> lane & 1ull) { lds.queue[slot][0] = A; lds.queue[slot][1] = B; }
+        qn += cnt;
+    });
+    if (qn > 0 || first) flush();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -851,7 +893,9 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
 }
 
 template <int C, int MASK>
-constexpr int bwd_waves() { return (C == 2 && MASK == 15) ? 3 : PIGS_BWD_WAVES; }   // 3 waves: no spills
+constexpr int bwd_waves() {      // the widest gradient sets get 3 waves (168 VGPRs): no spills
+    return ((C == 2 && (MASK == 7 || MASK == 8 || MASK == 15)) || (C == 1 && MASK == 15)) ? 3 : PIGS_BWD_WAVES;
+}
 template <int C, int MASK>
 __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void binned_backward_kernel(PlanView pv, const float* __restrict__ G0p,
                                                               const float* __restrict__ G1p,
@@ -870,18 +914,15 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void binned_backward_k
     const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
     const float INF = __builtin_huge_valf();
 
-    for (uint32_t base = sbeg; base < send; base += 64) {
+    // the points and incoming gradients of one 64-point chunk of the cell; lanes without a point
+    // sit on a corner of the box and contribute nothing
+    auto load_chunk = [&](uint32_t base, float bx0, float by0, float* s, Gsym<float, 2, C, MASK>& G) {
         const bool valid = base + lane < send;
-        SPoint sp = {0.f, 0.f, 0u};
+        SPoint sp = {bx0, by0, 0u};
         if (valid) sp = pv.spts[base + lane];
-        float s[2] = {sp.x, sp.y};
-        float bx0 = valid ? s[0] : INF, bx1 = valid ? s[0] : -INF, by0 = valid ? s[1] : INF, by1 = valid ? s[1] : -INF;
-        wave_box_dpp(bx0, bx1, by0, by1);
-        if (!valid) { s[0] = bx0; s[1] = by0; }
-
-        Gsym<float, 2, C, MASK> G;
+        s[0] = sp.x; s[1] = sp.y;
         G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
-        if (!valid) {   // lanes without a point contribute nothing
+        if (!valid) {
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
                 G.g0[ch] = 0.f;
@@ -890,24 +931,47 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void binned_backward_k
                 G.g3[0][ch] = G.g3[1][ch] = G.g3[2][ch] = G.g3[3][ch] = 0.f;
             }
         }
-        int qn = 0;
-        traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.t,
-                 [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
-            const int cnt = __builtin_popcountll(mask);
-            if (qn + cnt > QCAP_BWD) {
-                backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
-                qn = 0;
-            }
-            const int slot = qn + lanes_below(mask);
-            if (mask >> lane & 1ull) {
-                lds.t.queue[slot][0] = A;
-                lds.t.queue[slot][1] = B;
-                lds.qj[slot] = j;
-            }
-            qn += cnt;
-        });
-        backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
+    };
+    // box of ALL the cell's points: a cell holding more than 64 is still traversed once, and every
+    // queue flush is reduced for each of its 64-point chunks in turn
+    float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
+    for (uint32_t base = sbeg; base < send; base += 64) {
+        if (base + lane < send) {
+            const SPoint q = pv.spts[base + lane];
+            bx0 = fminf(bx0, q.x); bx1 = fmaxf(bx1, q.x);
+            by0 = fminf(by0, q.y); by1 = fmaxf(by1, q.y);
+        }
     }
+    wave_box_dpp(bx0, bx1, by0, by1);
+    const bool single = send - sbeg <= 64;          // the usual cell: its chunk stays in registers
+    float s[2];
+    Gsym<float, 2, C, MASK> G;
+    if (single) load_chunk(sbeg, bx0, by0, s, G);
+    int qn = 0;
+    auto flush = [&]() {
+        if (single) {
+            backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
+        } else {
+            for (uint32_t base = sbeg; base < send; base += 64) {
+                load_chunk(base, bx0, by0, s, G);
+                backward_queue<C, MASK>(s, G, lds, qn, lane, pv.gacc, pv.N);
+            }
+        }
+        qn = 0;
+    };
+    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.t,
+             [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
+        const int cnt = __builtin_popcountll(mask);
+        if (qn + cnt > QCAP_BWD) flush();
+        const int slot = qn + lanes_below(mask);
+        if (mask >> lane & 1ull) {
+            lds.t.queue[slot][0] = A;
+            lds.t.queue[slot][1] = B;
+            lds.qj[slot] = j;
+        }
+        qn += cnt;
+    });
+    flush();
 }
 
 template <int C>

@@ -178,6 +178,60 @@ __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict
     }
 }
 
+// Inverse of fwd_store: read the partial sums of point m back into the accumulators (a cell with
+// more than 64 points evaluates each queue flush for every 64-point chunk and parks the partial
+// sums in the output rows in between).  Null outputs were never stored and are not wanted: zero.
+template <typename T, int D, int C, int MASK>
+__device__ __forceinline__ void fwd_load(T* acc, int64_t m, const T* __restrict__ o0, const T* __restrict__ o1,
+                                         const T* __restrict__ o2, const T* __restrict__ o3) {
+    using L = FwdLayout<D, C, MASK>;
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = T(0);
+    if constexpr ((MASK & ORD0) != 0) {
+        if (o0) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[L::O0 + ch] = o0[m * C + ch];
+        }
+    }
+    if constexpr ((MASK & ORD1) != 0) {
+        if (o1) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) acc[L::O1 + i * C + ch] = -o1[(m * D + i) * C + ch];
+        }
+    }
+    if constexpr ((MASK & ORD2) != 0) {
+        if (o2) {
+#pragma unroll
+            for (int k = 0; k < Sym<D>::NF; ++k)        // (0,0), (0,1), (1,1): first index 0 until the last
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const int i = k == Sym<D>::NF - 1 ? D - 1 : 0, j = k - i;
+                    acc[L::O2 + k * C + ch] = o2[((m * D + i) * D + j) * C + ch];
+                }
+        }
+    }
+    if constexpr ((MASK & ORD2T) != 0) {
+        if (o2) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[L::O2 + ch] = o2[m * C + ch];
+        }
+    }
+    if constexpr ((MASK & ORD3) != 0) {
+        if (o3) {
+#pragma unroll
+            for (int k = 0; k < Sym<D>::N3; ++k)        // (0,0,0), (0,0,1), (0,1,1), (1,1,1)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const int a = k >= 3 ? 1 : 0, b = k >= 2 ? 1 : 0, c3 = k >= 1 ? 1 : 0;     // D = 2
+                    const int i = D == 1 ? 0 : a, j = D == 1 ? 0 : b, l = D == 1 ? 0 : c3;
+                    acc[L::O3 + k * C + ch] = o3[(((m * D + i) * D + j) * D + l) * C + ch];
+                }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward (VJP) of the selected outputs wrt (means, flat conics, values) for one pair.
 //
