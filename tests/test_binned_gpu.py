@@ -298,3 +298,37 @@ def test_config4_shard_of_4096sq_grid(Sampler):
         parts.append(torch.autograd.grad(o, params, grad_outputs=[x[lo:lo + half] for x in gouts]))
     for w, a, b in zip(whole, parts[0], parts[1]):
         assert float((a + b - w).abs().max()) / float(w.abs().max()) < TOL
+
+
+@pytest.mark.parametrize("c,orders", [(1, (0, 1, 2)), (2, (0, 1, 2, 3)), (1, (0, 1, "lap"))])
+def test_crowded_cell_many_flushes(Sampler, c, orders):
+    """Hundreds of points in one sample cell AND hundreds of Gaussians reaching it: the cell is
+    traversed once, its queue (128 records forward, 64 backward) is flushed several times, and
+    every flush is evaluated for each 64-point chunk with the partial sums parked in the output
+    rows in between."""
+    rng = np.random.default_rng(11)
+    N = 700
+    means, con, values = random_gaussians(rng, N, c, log_sigma_mean=-1.6, log_sigma_std=0.2, lo=-0.3, hi=0.3)
+    crowd = rng.uniform(-0.004, 0.004, (450, 2)) + np.array([0.05, -0.02])
+    samples = np.concatenate((crowd, rng.uniform(-1, 1, (2500, 2))))
+    rng.shuffle(samples)
+    if "lap" not in orders:
+        check_case(Sampler, means, con, values, samples, orders=orders)
+        return
+    t = [dev32(a) for a in (means, values, con, samples)]
+    for x in t[:3]:
+        x.requires_grad_(True)
+    s = Sampler(True, backend="binned", fuse="none")
+    s.preprocess(t[0], t[1], None, t[2], t[3])
+    u, ux, lap = s.sample(orders)
+    args = [x.detach().cpu().double().numpy() for x in (t[0], t[2], t[1], t[3])]
+    exp = c_oracle.forward(*args, orders=(0, 1, 2))
+    elap = exp[2][:, 0, 0, :] + exp[2][:, 1, 1, :]
+    assert rel(u, exp[0]) < TOL and rel(ux, exp[1]) < TOL and rel(lap, elap) < TOL
+    r = rng.uniform(-1, 1, elap.shape)
+    (lap * dev32(r)).sum().backward()
+    gH = np.zeros_like(exp[2])
+    gH[:, 0, 0, :] = r
+    gH[:, 1, 1, :] = r
+    em, ec, ev = c_oracle.backward(*args, {2: gH})
+    assert rel(t[0].grad, em) < TOL and rel(t[1].grad, ev) < TOL and rel(t[2].grad, ec) < TOL
