@@ -871,7 +871,7 @@ __device__ __forceinline__ void backward_queue(const float* s, const Gsym<float,
             const Rec r = make_rec(lds.t.queue[k0 + u][0], lds.t.queue[k0 + u][1]);
 #pragma unroll
             for (int k = 0; k < NV; ++k) part[u][k] = 0.f;
-            bwd_accumulate<float, 2, C, MASK>(part[u], s, r.mu, r.con, r.v, G);
+            bwd_accumulate<float, 2, C, MASK, (MASK & ORD3) != 0>(part[u], s, r.mu, r.con, r.v, G);
         }
         float y[NV];
         butterfly_group<3, NV>(part, 0, y);

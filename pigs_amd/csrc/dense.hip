@@ -127,8 +127,8 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
         Gsym<T, D, C, MASK> Ga, Gb;
         Ga.load(m, G0, G1, G2, G3);
         Gb.load(m + 1, G0, G1, G2, G3);
-        bwd_accumulate<T, D, C, MASK>(acc, s0, mu, con, v, Ga);
-        bwd_accumulate<T, D, C, MASK>(acc, s1, mu, con, v, Gb);
+        bwd_accumulate<T, D, C, MASK, true>(acc, s0, mu, con, v, Ga);
+        bwd_accumulate<T, D, C, MASK, true>(acc, s1, mu, con, v, Gb);
     }
     if (m < m_end) {                       // odd point of this wave's last pair
         T s0[D];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
         for (int i = 0; i < D; ++i) s0[i] = samples[m * D + i];
         Gsym<T, D, C, MASK> Ga;
         Ga.load(m, G0, G1, G2, G3);
-        bwd_accumulate<T, D, C, MASK>(acc, s0, mu, con, v, Ga);
+        bwd_accumulate<T, D, C, MASK, true>(acc, s0, mu, con, v, Ga);
     }
 
     if constexpr (NW > 1) {

@@ -295,13 +295,26 @@ template <int D, int C> struct BwdLayout {
     static constexpr int N = D + Sym<D>::NF + C;
 };
 
-template <typename T, int D, int C, int MASK>
+// FAR_GUARD (the dense kernels, which meet every pair, and the binned third-derivative backward,
+// whose waves evaluate a queued Gaussian for all 64 points of the cell): where g has underflowed
+// to zero the polynomial factors can overflow (p^4 C ~ 1e38 for sigma ~ 1e-4 of the distance)
+// and 0 * inf would poison the sums; such a pair contributes exactly nothing, so its x and p are
+// zeroed (v_exp_f32 flushes denormals: g is either above 1e-38 or exactly 0).
+template <typename T, int D, int C, int MASK, bool FAR_GUARD = false>
 __device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, const T* con, const T* v,
                                                const Gsym<T, D, C, MASK>& G) {
     using L = BwdLayout<D, C>;
     Pair<T, D> pr;
     pr.eval(s, mu, con);
     const T g = pr.g;
+    if constexpr (FAR_GUARD) {
+        const bool live = g > T(0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            pr.p[i] = live ? pr.p[i] : T(0);
+            pr.x[i] = live ? pr.x[i] : T(0);
+        }
+    }
     if constexpr (D == 1) {
         const T p = pr.p[0], x = pr.x[0], a = con[0];
         const T t2 = fma_<T>(p, p, -a);        // p^2 - a

@@ -1,6 +1,8 @@
 """GPU fuzz: the binned path against the dense HIP path (itself pinned to the oracle) on random
 problem shapes -- sizes, scales over several orders of magnitude, strong anisotropy, clustered
 and duplicated points, Gaussians far outside the sampled region."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,10 +48,14 @@ def make_case(rng):
     return means, values, con, pts
 
 
-@pytest.mark.parametrize("seed", range(24))
+SEEDS = int(os.environ.get("PIGS_FUZZ_SEEDS", "60"))     # a longer campaign: PIGS_FUZZ_SEEDS=4000 pytest ... (passes)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_binned_matches_dense(Sampler, seed):
     rng = np.random.default_rng(1000 + seed)
     means, values, con, pts = make_case(rng)
+    orders = (0, 1, "lap") if seed % 3 == 2 else (0, 1, 2, 3)
     outs, grads = {}, {}
     for backend in ("dense", "binned"):
         t = [torch.tensor(a, dtype=torch.float32, device="cuda") for a in (means, values, con, pts)]
@@ -57,17 +63,28 @@ def test_binned_matches_dense(Sampler, seed):
             x.requires_grad_(True)
         s = Sampler(True, backend=backend, fuse="all")
         s.preprocess(t[0], t[1], None, t[2], t[3])
-        o = s.sample((0, 1, 2, 3))
+        o = s.sample(orders)
         torch.manual_seed(seed)
         loss = sum((x * torch.randn_like(x)).sum() for x in o)
         loss.backward()
         outs[backend] = [x.detach() for x in o]
         grads[backend] = [x.grad for x in t[:3]]
-    for k, (a, b) in enumerate(zip(outs["dense"], outs["binned"])):
-        scale = float(a.abs().max())
-        assert torch.isfinite(b).all()
-        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-30, ("order", k, seed)
+    # The cut-off drops terms below e^(-q_max/2) poly(q_max) of the TERM's own scale, which for
+    # derivative order k is |v| lambda^(k/2) (lambda = the conic's larger eigenvalue = 1 / sigma_min^2).
+    # The bars are relative to the outputs' maxima or to that scale, whichever is larger: the two agree
+    # when some sample point sits in the core of the sharpest Gaussian, and where none does (sparse
+    # points, every point in the tails) the outputs' maxima understate what was truncated.
+    lam = (con[:, 0] + con[:, 2]) / 2 + np.sqrt(((con[:, 0] - con[:, 2]) / 2) ** 2 + con[:, 1] ** 2)
+    vmax = np.abs(values).max(axis=1)
+    term = {k: float((vmax * lam ** (k / 2)).max()) for k in (0, 1, 2, 3)}
+    term["lap"] = term[2]
+    under = 1.0
+    for o, a, b in zip(orders, outs["dense"], outs["binned"]):
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), ("order", o, seed)
+        top = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * max(top, term[o]) + 1e-30, ("order", o, seed)
+        under = max(under, term[o] / max(top, 1e-30))
     for k, (a, b) in enumerate(zip(grads["dense"], grads["binned"])):
-        scale = float(a.abs().max())
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), ("grad", k, seed)
         # random-sign weights cancel in the gradient sums: fp32 accumulation-order noise only
-        assert float((a - b).abs().max()) <= 5e-5 * scale + 1e-30, ("grad", k, seed)
+        assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()) * under + 1e-30, ("grad", k, seed)
