@@ -67,3 +67,35 @@ def test_captured_step_replays_on_new_parameters(hip_lib, backend, n, res):
         assert rel(grads[0], em) < TOL, (trial, "means", rel(grads[0], em))
         assert rel(grads[1], ev) < TOL, (trial, "values", rel(grads[1], ev))
         assert rel(grads[2], ec) < TOL, (trial, "conics", rel(grads[2], ec))
+
+
+def test_graphed_step_helper(hip_lib):
+    """pigs_amd.graphs.GraphedStep: the capture recipe as a helper, replayed on updated parameters."""
+    from diff_gaussian_sampling import GaussianSampler
+    from pigs_amd.graphs import GraphedStep
+    dev = torch.device("cuda")
+    gs = synthetic.lattice_gaussians(10, 10, 0.9, seed=4)
+    samples = synthetic.grid_samples(24).float().to(dev)
+    sampler = GaussianSampler(False)
+
+    def make_inputs():
+        return tuple(gs[k].float().to(dev).requires_grad_(True) for k in ("means", "values", "conics"))
+
+    def fn(means, values, conics):
+        sampler.preprocess(means, values, None, conics, samples)
+        u, ux, lap = sampler.sample((0, 1, "lap"))
+        loss = ((u - 0.1 * lap) ** 2).mean() + (ux ** 2).mean()
+        return (loss,) + torch.autograd.grad(loss, (means, values, conics))
+
+    step = GraphedStep(fn, make_inputs)
+    rng = np.random.default_rng(3)
+    for trial in range(4):
+        with torch.no_grad():
+            step.inputs[1].copy_(torch.as_tensor(rng.uniform(-1, 1, step.inputs[1].shape), dtype=torch.float32, device=dev))
+        loss, gm, gv, gc = step()
+        torch.cuda.synchronize()
+        means, values, conics = (x.detach().clone().requires_grad_(True) for x in step.inputs)
+        eager = fn(means, values, conics)          # the same step issued eagerly on the new values
+        for a, b in zip((loss, gm, gv, gc), eager):
+            a, b = a.detach(), b.detach()
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30, trial
