@@ -34,8 +34,8 @@ VALU_PAIR_PEAK = 3.6e12    # pairs/s: 157.3 TFLOP/s fp32 / 2 / ~22 issue slots p
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
     ap.add_argument("--kappa", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
