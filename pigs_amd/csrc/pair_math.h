@@ -69,6 +69,13 @@ __device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, 
     using L = FwdLayout<D, C, MASK>;
     Pair<T, D> pr;
     pr.eval(s, mu, con);
+    if constexpr ((MASK & ORD3) != 0) {
+        // a pair whose g has underflowed to zero contributes nothing, but its cubic factor can
+        // overflow (|p| > 7e12: conics of 1e12 from |rho| -> 1) and 0 * inf would poison the sum
+        const bool live = pr.g > T(0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) pr.p[i] = live ? pr.p[i] : T(0);
+    }
     if constexpr (D == 1) {
         const T p = pr.p[0];
         T t2 = 0, t3 = 0;

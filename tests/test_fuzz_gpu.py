@@ -48,7 +48,7 @@ def make_case(rng):
     return means, values, con, pts
 
 
-SEEDS = int(os.environ.get("PIGS_FUZZ_SEEDS", "60"))     # a longer campaign: PIGS_FUZZ_SEEDS=4000 pytest ... (passes)
+SEEDS = int(os.environ.get("PIGS_FUZZ_SEEDS", "60"))     # a longer campaign: PIGS_FUZZ_SEEDS=20000 pytest ... (passes)
 
 
 @pytest.mark.parametrize("seed", range(SEEDS))
@@ -78,11 +78,19 @@ def test_binned_matches_dense(Sampler, seed):
     vmax = np.abs(values).max(axis=1)
     term = {k: float((vmax * lam ** (k / 2)).max()) for k in (0, 1, 2, 3)}
     term["lap"] = term[2]
+    # float32 sums of many overlapping terms of random sign: the two paths add them in different
+    # orders, so their difference scales with sum |term| / |sum term| -- measured on order 0 with
+    # |values| -- times the float32 epsilon; the bars widen once that ratio passes 50
+    sa = Sampler(False, backend="dense")
+    ta = [torch.tensor(a, dtype=torch.float32, device="cuda") for a in (means, np.abs(values), con, pts)]
+    sa.preprocess(ta[0], ta[1], None, ta[2], ta[3])
+    cond = float(sa.sample_gaussians().max()) / max(float(outs["dense"][0].abs().max()), 1e-30)
+    slack = max(1.0, cond / 50.0)
     under = 1.0
     for o, a, b in zip(orders, outs["dense"], outs["binned"]):
         assert torch.isfinite(a).all() and torch.isfinite(b).all(), ("order", o, seed)
         top = float(a.abs().max())
-        assert float((a - b).abs().max()) <= 1e-5 * max(top, term[o]) + 1e-30, ("order", o, seed)
+        assert float((a - b).abs().max()) <= 1e-5 * slack * max(top, term[o]) + 1e-30, ("order", o, seed)
         under = max(under, term[o] / max(top, 1e-30))
     for k, (a, b) in enumerate(zip(grads["dense"], grads["binned"])):
         assert torch.isfinite(a).all() and torch.isfinite(b).all(), ("grad", k, seed)
