@@ -13,7 +13,7 @@
 // the points' original indices) plus record reads that mostly hit L2.
 //
 // Build-time knobs (defaults measured on MI355X): PIGS_FWD_WAVES, PIGS_FWD_UNROLL,
-// PIGS_FWD_BLOCK_WAVES, PIGS_TRAV_STEPS, PIGS_BWD_WAVES; PIGS_STAMPS=1 builds the
+// PIGS_FWD_BLOCK_WAVES, PIGS_FWD_QCAP, PIGS_TRAV_STEPS, PIGS_BWD_WAVES, PIGS_XCD_CHUNK; PIGS_STAMPS=1 builds the
 // diagnostic variant read by tools/stamps.py.
 #include "pair_math.h"
 #include "plan.h"
@@ -440,7 +440,10 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mas
 //      prefetched
 //   6. outputs stored through the point's original index.
 // ------------------------------------------------------------------------------------------
-constexpr int QCAP = 128;   // accepted records queued per wave before an evaluation run
+#ifndef PIGS_FWD_QCAP
+#define PIGS_FWD_QCAP 128
+#endif
+constexpr int QCAP = PIGS_FWD_QCAP;   // accepted records queued per wave before an evaluation run
 
 constexpr int CCAP = 256;   // bbox-accepted candidate indices buffered per wave before the exact test
 
