@@ -50,6 +50,6 @@ table[key] = {
            "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB is the corrected upper figure, hbm_bytes_raw the "
            "uncorrected one.",
 }
-table["all_kernels"] = allk
+table["all_kernels"] = allk      # other keys of the table (e.g. fetch_size_calibration) are kept
 json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(table[key], indent=1))
