@@ -13,6 +13,7 @@
  *                         .sample_gaussians_third_derivative()              (model_pn.py:654,778; test_pde.py:53)
  *   pigs_sample_backward  autograd backward of those outputs wrt (means, values, conics)
  *                         (test_derivatives.py:123,214-215,349-352; main_pn.py:220; test_no_mlp.py:146)
+ *   pigs_samples_build,
  *   pigs_plan_*           GaussianSampler.preprocess(means, values, covariances, conics, samples)
  *                         (model_pn.py:648,768,784; test_gaussian_sampling.py:56; test_1d.py:30)
  *
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 3
+#define PIGS_ABI_VERSION 4
 
 enum pigs_status {
     PIGS_OK = 0,
@@ -88,29 +89,54 @@ int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, c
                                     void* g_scaling, void* g_transform, void* stream);
 
 /*
- * Binned ("plan") path -- float32, d = 2, c <= 2.  preprocess() builds a plan in a caller-owned
- * device workspace: Gaussians binned by centre into a multi-level cell grid (packed, sorted
- * 32-byte records), sample points sorted into 64-point cells.  The sampling entry points then
- * evaluate, for every point, only the Gaussians whose q <= q_max ellipse reaches the point's
- * cell (dropped terms are below exp(-q_max/2) of a term's scale; q_max = 36 -> 1.5e-8).
- * The workspace is opaque, position independent device memory of pigs_plan_workspace_bytes()
- * bytes (256-byte aligned); the same (N, M, c, q_max) must be passed to every call on it.
- * pigs_plan_backward uses scratch inside the workspace: calls sharing a workspace must be
- * stream ordered.
+ * Binned ("plan") path -- float32, d = 2, c <= 2.  preprocess() builds, in caller-owned device
+ * memory, two position independent workspaces:
+ *
+ *   SAMPLES workspace (pigs_samples_workspace_bytes(M) bytes, 256-byte aligned): the sample points
+ *     sorted into ~16-point cells; tiles of 64 / groups of 16 consecutive sorted points are the
+ *     units of work.  Built from `samples` alone and immutable afterwards, so it may be shared by
+ *     any number of plans: the reference re-binds new Gaussians to an unchanged sample set on every
+ *     step of a roll-out (main_pn.py:317-324), and so does any fixed collocation grid.
+ *   PLAN workspace (pigs_plan_workspace_bytes(N, M, c) bytes): the Gaussians binned by centre into a
+ *     multi-level cell grid (packed, sorted 32-byte records) and, for every tile, the list of
+ *     Gaussians whose q <= q_max ellipse reaches the tile (with the 16-point groups each one
+ *     reaches).  Forward, backward and every further sample_*() of the same preprocess() read the
+ *     lists; none walks the grid again.
+ *
+ * The sampling entry points evaluate, for every point, only the Gaussians whose q <= q_max ellipse
+ * reaches the bounding box of the point's group (dropped terms are below exp(-q_max/2) of a term's
+ * scale; q_max = 36 -> 1.5e-8).  The same (N, M, c, q_max) and the same samples workspace must be
+ * passed to every call on a plan workspace.  pigs_plan_backward uses scratch inside the plan
+ * workspace: calls sharing one must be stream ordered.
  */
+size_t pigs_samples_workspace_bytes(int64_t M);                  /* 0 = unsupported size */
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsupported sizes */
 
-int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                    const void* means, const void* conics, const void* values,
-                    const void* samples, void* stream);
+/* samples workspace alone (4 launches) */
+int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream);
 
-int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
+/* plan workspace; build_samples != 0 also (re)builds the samples workspace from `samples` in the
+ * same launches (5 in all), build_samples == 0 requires a samples workspace that is already
+ * built, or being built earlier on the same stream (`samples` is not read then; 5 launches). */
+int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
+                    int build_samples, int64_t N, int64_t M, int c, float q_max,
+                    const void* means, const void* conics, const void* values, const void* samples, void* stream);
+
+int pigs_plan_forward(void* workspace, size_t workspace_bytes, const void* samples_ws, size_t samples_ws_bytes,
+                      int64_t N, int64_t M, int c, float q_max,
                       int orders_mask, void* out0, void* out1, void* out2, void* out3, void* stream);
 
-int pigs_plan_backward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                       int orders_mask,
+int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samples_ws, size_t samples_ws_bytes,
+                       int64_t N, int64_t M, int c, float q_max, int orders_mask,
                        const void* gout0, const void* gout1, const void* gout2, const void* gout3,
                        void* g_means, void* g_conics, void* g_values, void* stream);
+
+/* Byte offset, inside a samples / plan workspace, of a uint32 that a build leaves at 0 and sets to
+ * non-zero when its in-kernel scan gave up waiting for a predecessor workgroup (a result built
+ * from such a workspace is invalid; never observed -- the wait is bounded so that a stuck
+ * predecessor is an error instead of a hung device).  For debugging hosts to read back. */
+size_t pigs_samples_error_offset(void);
+size_t pigs_plan_error_offset(void);
 
 #ifdef __cplusplus
 }

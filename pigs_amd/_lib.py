@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIGS_AMD_LIB") or os.path.join(HERE, "libpigs_amd.so")
 
 PIGS_F32, PIGS_F64 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -30,11 +30,17 @@ SIGNATURES = {
     "pigs_sample_backward": (_i, [_i, _i, _i, _i, _i64, _i64] + [_vp] * 4 + [_vp] * 4 + [_vp] * 3 + [_vp]),
     "pigs_build_covariances": (_i, [_i, _i64] + [_vp] * 4 + [_vp]),
     "pigs_build_covariances_backward": (_i, [_i, _i64] + [_vp] * 6 + [_vp]),
+    "pigs_samples_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
-    "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float] + [_vp] * 4 + [_vp]),
-    "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4 + [_vp]),
-    "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i] + [_vp] * 4
-                           + [_vp] * 3 + [_vp]),
+    "pigs_samples_error_offset": (ctypes.c_size_t, []),
+    "pigs_plan_error_offset": (ctypes.c_size_t, []),
+    "pigs_samples_build": (_i, [_vp, ctypes.c_size_t, _i64, _vp, _vp]),
+    "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _i64, _i64, _i, ctypes.c_float]
+                        + [_vp] * 4 + [_vp]),
+    "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i]
+                          + [_vp] * 4 + [_vp]),
+    "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i]
+                           + [_vp] * 4 + [_vp] * 3 + [_vp]),
 }
 
 _lib = None

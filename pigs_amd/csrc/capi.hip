@@ -84,36 +84,47 @@ int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, c
                                 (hipStream_t)stream);
 }
 
+size_t pigs_samples_workspace_bytes(int64_t M) { return samples_workspace_bytes(M); }
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c) { return plan_workspace_bytes(N, M, c); }
+size_t pigs_samples_error_offset(void) { return samples_error_offset(); }
+size_t pigs_plan_error_offset(void) { return plan_error_offset(); }
 
-int pigs_plan_build(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c,
-                    float q_max, const void* means, const void* conics, const void* values, const void* samples,
-                    void* stream) {
-    if (N < 0 || M < 0 || c < 1) return PIGS_ERR_INVALID;
-    if (!means || !conics || !values || !samples) return PIGS_ERR_INVALID;
-    return plan_build(workspace, workspace_bytes, N, M, c, q_max, means, conics, values, samples,
-                      (hipStream_t)stream);
+int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream) {
+    if (M < 0 || !samples) return PIGS_ERR_INVALID;
+    return samples_build(samples_ws, samples_ws_bytes, M, samples, (hipStream_t)stream);
 }
 
-int pigs_plan_forward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                      int orders_mask, void* out0, void* out1, void* out2, void* out3, void* stream) {
+int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
+                    int build_samples, int64_t N, int64_t M, int c, float q_max, const void* means,
+                    const void* conics, const void* values, const void* samples, void* stream) {
+    if (N < 0 || M < 0 || c < 1) return PIGS_ERR_INVALID;
+    if (!means || !conics || !values || (build_samples && !samples)) return PIGS_ERR_INVALID;
+    return plan_build(workspace, workspace_bytes, samples_ws, samples_ws_bytes, build_samples, N, M, c, q_max, means,
+                      conics, values, samples, (hipStream_t)stream);
+}
+
+int pigs_plan_forward(void* workspace, size_t workspace_bytes, const void* samples_ws, size_t samples_ws_bytes,
+                      int64_t N, int64_t M, int c, float q_max, int orders_mask, void* out0, void* out1, void* out2,
+                      void* out3, void* stream) {
     if (!mask_valid(orders_mask)) return PIGS_ERR_INVALID;
     void* outs[4] = {out0, out1, out2, out3};
     for (int k = 0; k < 4; ++k)
         if (mask_uses_slot(orders_mask, k) && !outs[k]) return PIGS_ERR_INVALID;
-    return plan_forward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, outs, (hipStream_t)stream);
+    return plan_forward(workspace, workspace_bytes, samples_ws, samples_ws_bytes, N, M, c, q_max, orders_mask, outs,
+                        (hipStream_t)stream);
 }
 
-int pigs_plan_backward(void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int c, float q_max,
-                       int orders_mask, const void* gout0, const void* gout1, const void* gout2,
-                       const void* gout3, void* g_means, void* g_conics, void* g_values, void* stream) {
+int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samples_ws, size_t samples_ws_bytes,
+                       int64_t N, int64_t M, int c, float q_max, int orders_mask, const void* gout0,
+                       const void* gout1, const void* gout2, const void* gout3, void* g_means, void* g_conics,
+                       void* g_values, void* stream) {
     if (!mask_valid(orders_mask)) return PIGS_ERR_INVALID;
     const void* gs[4] = {gout0, gout1, gout2, gout3};
     for (int k = 0; k < 4; ++k)
         if (mask_uses_slot(orders_mask, k) && !gs[k]) return PIGS_ERR_INVALID;
     if (!g_means || !g_conics || !g_values) return PIGS_ERR_INVALID;
-    return plan_backward(workspace, workspace_bytes, N, M, c, q_max, orders_mask, gs, g_means, g_conics, g_values,
-                         (hipStream_t)stream);
+    return plan_backward(workspace, workspace_bytes, samples_ws, samples_ws_bytes, N, M, c, q_max, orders_mask, gs,
+                         g_means, g_conics, g_values, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -22,15 +22,20 @@ int dense_dispatch(bool backward, const SampleArgs& a, hipStream_t stream);
 int covariances_dispatch(bool backward, int dtype, int64_t N, const void* scaling, const void* transform,
                          const void* a, const void* b, void* o0, void* o1, hipStream_t stream);
 
-// binned.hip
+// plan.hip
+size_t samples_workspace_bytes(int64_t M);
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c);
-int plan_build(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max,
-               const void* means, const void* conics, const void* values, const void* samples,
+int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream);
+int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int build_samples, int64_t N, int64_t M, int c,
+               float q_max, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream);
-int plan_forward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask, void* const* out,
-                 hipStream_t stream);
-int plan_backward(void* ws, size_t ws_bytes, int64_t N, int64_t M, int c, float q_max, int mask,
-                  const void* const* gout, void* g_means, void* g_conics, void* g_values, hipStream_t stream);
+int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
+                 float q_max, int mask, void* const* out, hipStream_t stream);
+int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
+                  float q_max, int mask, const void* const* gout, void* g_means, void* g_conics, void* g_values,
+                  hipStream_t stream);
+size_t samples_error_offset();
+size_t plan_error_offset();
 
 // Order masks: bit k < 4 = derivative order k (pointer slot k); bit 4 (16) = the TRACE of the order-2
 // output (the Laplacian), which takes pointer slot 2 in place of the full Hessian, [M][c].

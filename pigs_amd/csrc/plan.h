@@ -2,22 +2,38 @@
 //
 // What `GaussianSampler.preprocess(means, values, covariances, conics, samples)` builds
 // (call sites model_pn.py:648,768,784; the reference's own native preprocess is not visible --
-// this design is new):
+// this design is new).  Two workspaces, because the two halves change at different rates (the
+// reference re-binds new Gaussians to an unchanged sample set every step of a roll-out,
+// main_pn.py:317-324; a fixed collocation grid does the same in training):
 //
-//  * Gaussians are binned by their CENTRE into a multi-level uniform grid.  Level l has
-//    (G0 >> l)^2 square cells of side s0 * 2^l; a Gaussian whose q <= q_max ellipse has
-//    half-extent R = max(hx, hy) goes to the lowest level with R <= s_l (top level: one cell,
-//    anything larger).  Within a level the Gaussians are counting-sorted by cell (row-major),
-//    so "all Gaussians whose ellipse can reach a rectangle" is a handful of CONTIGUOUS ranges
-//    of packed 32-byte records: the cells within one cell of the rectangle, per level.
-//    Memory is static (N records + the cell table): no per-call allocation, no host sync.
-//  * Sample points are counting-sorted into square cells holding ~63 points (2x2-blocked cell
-//    order, so the four waves of a workgroup own a 2x2 block of cells); the sorted copy keeps
-//    each point's original index.  One wave = one cell = 64 lanes = 64 points.
+//  SAMPLES workspace (built from `samples` alone; immutable afterwards, shared by any number of
+//  plans):
+//    * the points counting-sorted into square FINE CELLS of ~16 points (4 x 4 points of a regular
+//      grid), cell ids ordered block (4x4 cells) > 2x2 > cell, each point keeping its index in the
+//      caller's array.  Position in the sorted array is all the sampling kernels use:
+//        TILE  = 64 consecutive sorted points = one wave   (a 2x2 block of cells on a grid)
+//        GROUP = 16 consecutive sorted points = one 16-lane DPP row of that wave (one cell)
+//      so every wave is full whatever the point distribution; only the tightness of the boxes
+//      depends on it.
+//
+//  PLAN workspace (built from the Gaussians + a SAMPLES workspace, once per preprocess):
+//    * Gaussians binned by their CENTRE into a multi-level uniform grid over the sample domain.
+//      Level l has (G0 >> l)^2 square cells of side s0 * 2^l; a Gaussian whose q <= q_max ellipse
+//      has half-extent R = max(hx, hy) goes to the lowest level with R <= s_l (top level: one
+//      cell).  Within a level the Gaussians are counting-sorted by cell (row-major), so "all
+//      Gaussians whose ellipse can reach a rectangle" is a handful of CONTIGUOUS ranges of packed
+//      32-byte records: the cells within one cell of the rectangle, per level.
+//    * per TILE the list of Gaussians whose ellipse reaches the bounding box of the tile's points
+//      (exact ellipse / rectangle test), each entry carrying a 4-bit mask of the tile's GROUPS
+//      whose own box it reaches: entry = sorted index | mask << 28.  Forward, backward and every
+//      further sample_* call of the same preprocess read these lists; none of them traverses the
+//      grid again.  A list that would not fit its slab (very wide Gaussians) is replaced by the
+//      grid's record ranges around the tile (every Gaussian in them is evaluated for the whole
+//      tile), and by the single range [0, N) when even those do not fit.
 //
 // Cut-off: a (point, Gaussian) pair is evaluated iff the Gaussian's ellipse q <= q_max reaches
-// the bounding box of the wave's points (exact ellipse/rectangle test).  Dropped terms are
-// < exp(-q_max/2) of the term's scale (q_max = 36: 1.5e-8; see DESIGN.md "Cut-off").
+// the bounding box of the point's 16-point group.  Dropped terms are < exp(-q_max/2) of the
+// term's scale (q_max = 36: 1.5e-8; see DESIGN.md "Cut-off").
 //
 // Correctness never depends on the grid domains: out-of-domain coordinates clamp to border
 // cells and queries clamp the same (monotone) way; only speed depends on them.
@@ -30,25 +46,30 @@ namespace pigs {
 constexpr int PLAN_MAX_LEVELS = 12;
 constexpr uint32_t PLAN_SCAN_BLOCK = 256 * 4;     // counters scanned per workgroup (one uint4 per thread)
 
-constexpr int PLAN_POINTS_PER_CELL = 63;   // target occupancy of a 64-lane sample cell: a regular grid then
-                                            // yields cells of 49..64 points (never a second pass); for Poisson
-                                            // counts the short second passes cost about what emptier cells would
+constexpr int TILE_POINTS = 64;            // one wave
+constexpr int GROUP_POINTS = 16;           // one DPP row
+constexpr int PLAN_POINTS_PER_CELL = 16;   // target occupancy of a fine sample cell: a regular res x res grid
+                                            // (res a multiple of 4) then yields exactly 4 x 4 points per cell
 
-// Per-workgroup partial bounding boxes written by the first build kernel (plain stores; same-
-// address atomics serialise at ~10 ns each, so no atomics here) and reduced again by every
-// workgroup of the second.
-constexpr int PLAN_BBOX_BLOCKS = 128;
-struct BoxPartial {
-    float g[4];   // Gaussian centres: min x, min y, max x, max y (+-inf when empty)
-    float s[4];   // sample points
-};
+// Per-workgroup partial bounding boxes of the sample points written by the first build kernel (plain
+// stores; same-address atomics serialise at ~10 ns each, so no atomics here) and reduced again by
+// every workgroup of the second.
+constexpr int PLAN_BBOX_BLOCKS = 256;
+
+// tile list entries: sorted Gaussian index | group mask << LIST_IDX_BITS
+constexpr int LIST_IDX_BITS = 28;
+constexpr uint32_t LIST_IDX_MASK = (1u << LIST_IDX_BITS) - 1u;
+// tile header: count | mode << 30
+constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u;
+constexpr int TILE_MODE_SHIFT = 30;
+constexpr uint32_t TILE_COUNT_MASK = (1u << TILE_MODE_SHIFT) - 1u;
 
 struct GaussGrid {
     float ox, oy, inv_s0, s0;
 };
 struct SampleGrid {
     float ox, oy, inv_w;
-    int nx, ny;   // even
+    int nx, ny;   // multiples of 4
 };
 // A sample point in sorted (cell) order: its coordinates and its index in the caller's array.
 struct SPoint {
@@ -56,32 +77,69 @@ struct SPoint {
     uint32_t m;
 };
 
-// Written once by the build (first bytes of the workspace), read by the sampling kernels.
-struct PlanParams {
-    GaussGrid gg;
+// Written once by the samples build (first bytes of the samples workspace).
+struct SampleParams {
+    float box[4];          // min x, min y, max x, max y of the finite sample coordinates (+-inf when none)
     SampleGrid sg;
-    uint32_t level_mask;
-    uint32_t level_off[PLAN_MAX_LEVELS + 1];   // first counter of every level (copy of PlanLayout::level_off:
-                                               // the sampling kernels index it by lane)
+    uint32_t scan_error;   // set when the scan's bounded spin ran out (never in a healthy run)
 };
 
-// Host+device view of the workspace (plain offsets; computed identically by every entry point
-// from (N, M, c) alone).
+// Written once per plan build (first bytes of the plan workspace), read by the sampling kernels.
+struct PlanParams {
+    GaussGrid gg;
+    uint32_t level_mask;
+    uint32_t level_off[PLAN_MAX_LEVELS + 1];   // first counter of every level (copy of PlanLayout::level_off:
+                                               // the traversal indexes it by lane)
+    uint32_t scan_error;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- samples workspace ------------------------------------------------------------------------
+struct SamplesLayout {
+    int64_t M;
+    uint32_t scells_cap;       // capacity (upper bound) of fine sample cells, multiple of 16
+    uint32_t scan_blocks;      // workgroups of the scan = ceil((scells_cap + 1) / PLAN_SCAN_BLOCK)
+    uint32_t ntiles;           // ceil(M / 64)
+    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_skey, off_spts, total_bytes;
+};
+
+inline SamplesLayout make_samples_layout(int64_t M) {
+    SamplesLayout p{};
+    p.M = M;
+    // fine cells: <= M/target + perimeter slack, rounded to whole 4x4 blocks
+    const int64_t base = M / PLAN_POINTS_PER_CELL + 1;
+    int64_t cap = base + base / 4 + 16 * (int64_t)(__builtin_sqrt((double)base) + 4) + 64;
+    cap = (cap + 15) / 16 * 16;
+    p.scells_cap = (uint32_t)cap;
+    p.scan_blocks = (p.scells_cap + 1 + PLAN_SCAN_BLOCK - 1) / PLAN_SCAN_BLOCK;
+    p.ntiles = (uint32_t)((M + TILE_POINTS - 1) / TILE_POINTS);
+    size_t o = 0;
+    p.off_params = o;   o = align_up(o + sizeof(SampleParams), 256);
+    p.off_boxes = o;    o = align_up(o + sizeof(float4) * PLAN_BBOX_BLOCKS, 256);
+    // counters and the scan's per-workgroup aggregates are adjacent: zeroed together
+    p.off_counts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
+    p.off_agg = o;      o = align_up(o + sizeof(uint64_t) * (size_t)p.scan_blocks, 256);
+    p.off_starts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
+    p.off_skey = o;     o = align_up(o + sizeof(uint2) * (size_t)M, 256);      // {cell id, rank in cell}
+    p.off_spts = o;     o = align_up(o + sizeof(SPoint) * (size_t)M, 256);
+    p.total_bytes = o;
+    return p;
+}
+
+// ---- plan workspace ---------------------------------------------------------------------------
 struct PlanLayout {
     int64_t N, M;
     int c;
     int G0, L;                 // finest Gaussian grid is G0 x G0; L levels
     uint32_t gcells;           // total Gaussian cell counters over all levels (padded: level_shift)
-    uint32_t scells_cap;       // capacity (upper bound) of sample cells, multiple of 4
-    uint32_t sbase;            // index of the first sample-cell counter (gcells rounded up to a 128-B line)
-    uint32_t ncounts;          // sbase + scells_cap
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
-    uint32_t scan_blocks;      // workgroups of the scan = ceil((ncounts + 1) / PLAN_SCAN_BLOCK)
-    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_gkey, off_skey, off_rec, off_box, off_g2o, off_spts, off_gacc,
-        total_bytes;
+    uint32_t scan_blocks;      // workgroups of the scan = ceil((gcells + 1) / PLAN_SCAN_BLOCK)
+    uint32_t ntiles;           // ceil(M / 64)
+    uint32_t list_cap;         // entries per tile slab, multiple of 64
+    size_t off_params, off_counts, off_agg, off_starts, off_gkey, off_rec, off_box, off_g2o, off_gacc, off_hdr,
+        off_lists, total_bytes;
 };
-
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Counter spacing of a level with `cells` cells: device-scope atomics on one 128-byte line
 // serialise (~10 ns each; tools/ubench/atomics2.hip: 1 280 packed counters take 5 atomics/ns,
@@ -91,6 +149,16 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 __host__ __device__ inline int level_shift(uint32_t cells) {     // cells: a power of two
     const int sh = 13 - (31 - __builtin_clz(cells | 1u));
     return sh < 0 ? 0 : sh > 5 ? 5 : sh;
+}
+
+// Slab of a tile's list: room for every Gaussian when N is small (such a list can never
+// overflow), 1 024 entries (64 bytes per sample point) beyond; what does not fit is kept as
+// record ranges (plan.h header).
+inline uint32_t list_cap_for(int64_t N) {
+    int64_t cap = (N + 63) / 64 * 64;
+    if (cap < 64) cap = 64;
+    if (cap > 1024) cap = 1024;
+    return (uint32_t)cap;
 }
 
 inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
@@ -108,62 +176,64 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
         const uint32_t gl = (uint32_t)(g >> l);
         off += (gl * gl) << level_shift(gl * gl);
     }
-    p.level_off[p.L] = off;
+    for (int l = p.L; l <= PLAN_MAX_LEVELS; ++l) p.level_off[l] = off;
     p.gcells = off;
-    // sample cells: <= M/target + perimeter slack, rounded to whole 2x2 blocks
-    int64_t cap = M / PLAN_POINTS_PER_CELL + 8 * (int64_t)(__builtin_sqrt((double)(M / PLAN_POINTS_PER_CELL + 1)) + 2) + 64;
-    cap = (cap + 3) / 4 * 4;         // whole 2x2 blocks
-    p.scells_cap = (uint32_t)cap;
-    p.sbase = (p.gcells + 31) / 32 * 32;
-    p.ncounts = p.sbase + p.scells_cap;
+    p.scan_blocks = (p.gcells + 1 + PLAN_SCAN_BLOCK - 1) / PLAN_SCAN_BLOCK;
+    p.ntiles = (uint32_t)((M + TILE_POINTS - 1) / TILE_POINTS);
+    p.list_cap = list_cap_for(N);
     size_t o = 0;
-    p.scan_blocks = (p.ncounts + 1 + PLAN_SCAN_BLOCK - 1) / PLAN_SCAN_BLOCK;
     p.off_params = o;   o = align_up(o + sizeof(PlanParams), 256);
-    p.off_boxes = o;    o = align_up(o + sizeof(BoxPartial) * PLAN_BBOX_BLOCKS, 256);
-    // counters and the scan's per-workgroup aggregates are adjacent: zeroed together
-    // (both arrays padded to whole scan blocks: the scan moves uint4s)
     p.off_counts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
     p.off_agg = o;      o = align_up(o + sizeof(uint64_t) * (size_t)p.scan_blocks, 256);
     p.off_starts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
     p.off_gkey = o;     o = align_up(o + sizeof(uint2) * (size_t)N, 256);      // {cell key, rank in cell}
-    p.off_skey = o;     o = align_up(o + sizeof(uint2) * (size_t)M, 256);
     p.off_rec = o;      o = align_up(o + 32 * (size_t)N, 256);
     p.off_box = o;      o = align_up(o + 16 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
-    p.off_spts = o;     o = align_up(o + sizeof(SPoint) * (size_t)M, 256);
     p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [8][N]
+    p.off_hdr = o;      o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles, 256);
+    p.off_lists = o;    o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles * p.list_cap, 256);
     p.total_bytes = o;
     return p;
 }
 
-// Device view: raw pointers + the scalars kernels need.
+// Device view of a samples workspace.
+struct SamplesView {
+    const SampleParams* params;
+    const SPoint* spts;           // sorted points: coordinates + original index
+    uint32_t M, ntiles;
+};
+
+// Device view of a plan workspace: raw pointers + the scalars kernels need.
 struct PlanView {
     const PlanParams* params;
-    const uint32_t* starts;       // [ncounts + 1] exclusive scan of the cell counters: Gaussian cells at
-                                  // [0, gcells), sample cells at [sbase, sbase + scells_cap)
+    const uint32_t* starts;       // [gcells + 1] exclusive scan of the Gaussian cell counters
     const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {b, c, v0, v1}  (c <= 2)
     const float4* gbox;           // [N] sorted: {mux, muy, hx, hy} = centre and half extents of the q <= q_max ellipse
     const uint32_t* g2o;          // sorted Gaussian -> original index
-    const SPoint* spts;           // sorted points: coordinates + original index
-    uint32_t N, M;
+    const uint32_t* hdr;          // [ntiles] count | mode << 30
+    const uint32_t* lists;        // [ntiles][list_cap]
+    uint32_t N, list_cap;
     int G0, L;
-    uint32_t sbase, scells_cap;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     float q_max;
     float* gacc;                  // backward scratch: [8][N] sorted-order gradient sums
 };
 
-// ---- grid geometry derived (identically by every thread) from the header's bounding boxes ----
+// ---- grid geometry derived (identically by every thread) from the sample bounding box ----
 
-// box = {min x, min y, max x, max y}; min > max (+-inf) when there were no finite points
+// box = {min x, min y, max x, max y}; min > max (+-inf) when there were no finite points.
+// The Gaussian grid spans the sample domain plus 1/16 of its extent on every side: centres
+// further out only matter through ellipses that reach back in, and clamp to the border cells.
 __device__ inline GaussGrid gauss_grid(const float* box, int G0) {
     GaussGrid g;
     const float x0 = box[0], y0 = box[1], x1 = box[2], y1 = box[3];
     float ext = fmaxf(x1 - x0, y1 - y0);
     if (!(ext > 0.f) || !(ext < 3.0e38f)) ext = 1.f;      // empty / single point / non-finite
-    g.ox = (x1 >= x0) ? x0 : 0.f;
-    g.oy = (y1 >= y0) ? y0 : 0.f;
-    g.s0 = ext * 1.0001f / (float)G0;
+    const float pad = ext * 0.0625f;
+    g.ox = ((x1 >= x0) ? x0 : 0.f) - pad;
+    g.oy = ((y1 >= y0) ? y0 : 0.f) - pad;
+    g.s0 = ext * 1.1251f / (float)G0;
     g.inv_s0 = 1.f / g.s0;
     return g;
 }
@@ -181,22 +251,25 @@ __device__ inline SampleGrid sample_grid(const float* box, uint32_t M, uint32_t 
     s.ox = (x1 >= x0) ? x0 : 0.f;
     s.oy = (y1 >= y0) ? y0 : 0.f;
     float w = sqrtf(ex * ey * (float)PLAN_POINTS_PER_CELL / (float)(M > 0 ? M : 1));
-    for (int it = 0; it < 16; ++it) {
-        s.nx = ((int)ceilf(ex / w) + 1) & ~1;
-        s.ny = ((int)ceilf(ey / w) + 1) & ~1;
-        if (s.nx < 2) s.nx = 2;
-        if (s.ny < 2) s.ny = 2;
+    for (int it = 0; it < 24; ++it) {
+        s.nx = ((int)ceilf(ex / w) + 3) & ~3;
+        s.ny = ((int)ceilf(ey / w) + 3) & ~3;
+        if (s.nx < 4) s.nx = 4;
+        if (s.ny < 4) s.ny = 4;
         if ((uint64_t)s.nx * (uint64_t)s.ny <= scells_cap) break;
         w *= 1.25f;
     }
-    if ((uint64_t)s.nx * (uint64_t)s.ny > scells_cap) { s.nx = 2; s.ny = 2; w = fmaxf(ex, ey); }  // never for sane input
+    if ((uint64_t)s.nx * (uint64_t)s.ny > scells_cap) { s.nx = 4; s.ny = 4; w = fmaxf(ex, ey); }  // never for sane input
     s.inv_w = 1.f / w;
     return s;
 }
 
-// 2x2-blocked cell id: the four cells of a block are consecutive (one workgroup = one block)
+// cell id ordered block (4x4 cells) > 2x2 > cell: the 16 cells of a block, and inside it the four
+// cells of each 2x2, are consecutive -- so are their points in the sorted array
 __device__ inline uint32_t sample_cell_id(int cx, int cy, int nx) {
-    return (uint32_t)((((cy >> 1) * (nx >> 1) + (cx >> 1)) << 2) | ((cy & 1) << 1) | (cx & 1));
+    const uint32_t block = (uint32_t)((cy >> 2) * (nx >> 2) + (cx >> 2));
+    const uint32_t in = (uint32_t)((((cy >> 1) & 1) << 3) | (((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
+    return (block << 4) | in;
 }
 
 }  // namespace pigs

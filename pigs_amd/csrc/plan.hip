@@ -1,0 +1,1165 @@
+// Binned (culled) sampler: preprocess (samples build + plan build) + forward + backward, float32, d = 2.
+// Data structures and the cut-off rule: plan.h.  Per-pair arithmetic: pair_math.h.
+//
+// Samples build = 4 launches (bbox partials -> cell key + rank -> scan -> scatter); plan build =
+// the same chain for the Gaussians (sharing the launches of a samples build that runs with it) +
+// one launch that walks the Gaussian grid once per 64-point tile and writes the tile's list.  No
+// memset, no host synchronisation, static memory.
+// Sampling kernels: one wave = one tile of 64 consecutive sorted points (lane = point), one DPP row =
+// one 16-point group.  The wave reads its list 64 entries at a time, gathers their 32-byte records
+// into wave-private LDS, splits the entries by their group masks into four per-row index lists
+// (ballot + mbcnt) and evaluates them row-wise: in one instruction every row works on its OWN
+// Gaussian, read from LDS with a row-uniform address.  No workgroup barriers; HBM traffic is the
+// point stream (sorted points in, outputs out through the points' original indices) plus list and
+// record reads that mostly hit L2.
+//
+// Build-time knobs (defaults measured on MI355X): PIGS_FWD_WAVES, PIGS_FWD_UNROLL,
+// PIGS_BWD_WAVES, PIGS_TRAV_STEPS, PIGS_XCD_CHUNK.
+#include "pair_math.h"
+#include "plan.h"
+#include "launch.h"
+
+#ifndef PIGS_FWD_WAVES
+#define PIGS_FWD_WAVES 8      // waves per SIMD the forward kernel's register budget is held to
+#endif
+#ifndef PIGS_FWD_UNROLL
+#define PIGS_FWD_UNROLL 2     // list rows evaluated per loop iteration
+#endif
+#ifndef PIGS_BWD_WAVES
+#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to
+#endif
+#ifndef PIGS_TRAV_STEPS
+#define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
+#endif
+
+namespace pigs {
+
+// ------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes, all active)
+// ------------------------------------------------------------------------------------------
+// DPP controls: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140, row_bcast15 = 0x142, row_bcast31 = 0x143.
+__device__ __forceinline__ float wave_min_bcast(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float wave_max_bcast(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int lanes_below(uint64_t mask) {   // set bits of mask below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// orders this wave's LDS accesses for the compiler (lanes exchange data through LDS without a
+// workgroup barrier: the LDS itself serves one wave's instructions in order)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------
+// preprocess kernels
+// ------------------------------------------------------------------------------------------
+struct BuildArgs {
+    // samples side
+    SampleParams* sparams;
+    float4* sboxes;       // [PLAN_BBOX_BLOCKS] per-workgroup partial boxes {min x, min y, max x, max y}
+    uint32_t* scounts;    // [s_scan_blocks * PLAN_SCAN_BLOCK] fine-cell counters, followed by the scan aggregates
+    unsigned long long* sagg;
+    uint32_t* sstarts;
+    uint2* skey;          // per point {cell id, rank inside the cell}
+    SPoint* spts;
+    const float* samples;
+    uint32_t M, scells_cap, s_scan_blocks, s_zero_words;
+    // plan side
+    PlanParams* params;
+    uint32_t* counts;     // [scan_blocks * PLAN_SCAN_BLOCK] Gaussian cell counters, followed by the scan aggregates
+    unsigned long long* agg;   // [scan_blocks] {1 << 32 | workgroup total}, zero before the scan
+    uint32_t* starts;     // [gcells + 1] exclusive scan of counts
+    uint2* gkey;          // per Gaussian {cell key, rank inside the cell}
+    float4* rec;
+    float4* gbox;
+    float* gacc;
+    uint32_t* g2o;
+    const float* means;
+    const float* conics;
+    const float* values;
+    uint32_t N;
+    int c, G0, L;
+    uint32_t scan_blocks, zero_words;
+    uint32_t level_off[PLAN_MAX_LEVELS + 1];
+    float q_max;
+    // which halves this build covers
+    int do_samples, do_plan;
+};
+
+__device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
+    uint4* p4 = (uint4*)p;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < words / 4; i += gridDim.x * 256) p4[i] = make_uint4(0, 0, 0, 0);
+}
+
+// Launch 1 of a samples build (PLAN_BBOX_BLOCKS workgroups): zero the cell counters (of the plan
+// too, when one is built alongside); per-workgroup bounding box of the sample points, 8 float4
+// loads (16 points) in flight per thread, written as a plain partial.
+__global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
+    __shared__ float sh[4][4];
+    zero_words(a.scounts, a.s_zero_words);
+    if (a.do_plan) zero_words(a.counts, a.zero_words);
+    const float INF = __builtin_huge_valf();
+    float x0 = INF, y0 = INF, x1 = -INF, y1 = -INF;
+    auto take = [&](float x, float y) {
+        if (fabsf(x) < INF) { x0 = fminf(x0, x); x1 = fmaxf(x1, x); }
+        if (fabsf(y) < INF) { y0 = fminf(y0, y); y1 = fmaxf(y1, y); }
+    };
+    const float4* pts2 = (const float4*)a.samples;
+    const float2* pts = (const float2*)a.samples;
+    const uint32_t n = a.M;
+    const uint32_t npair = n / 2;                 // float4 = two points
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npair; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t j = i + k * stride;
+            v[k] = pts2[j < npair ? j : i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
+    }
+    if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) take(pts[n - 1].x, pts[n - 1].y);
+    x0 = wave_min_bcast(x0); y0 = wave_min_bcast(y0);
+    x1 = wave_max_bcast(x1); y1 = wave_max_bcast(y1);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            x0 = fminf(x0, sh[w][0]); y0 = fminf(y0, sh[w][1]);
+            x1 = fmaxf(x1, sh[w][2]); y1 = fmaxf(y1, sh[w][3]);
+        }
+        a.sboxes[blockIdx.x] = make_float4(x0, y0, x1, y1);
+    }
+}
+
+// a plan built on an existing samples workspace has no bbox launch in front of it: its counters
+// are zeroed by this one
+__global__ __launch_bounds__(256) void plan_zero_kernel(BuildArgs a) { zero_words(a.counts, a.zero_words); }
+
+// every workgroup of the count kernel reduces the PLAN_BBOX_BLOCKS partials (4 KB, L2 resident)
+__device__ __forceinline__ void reduce_boxes(const float4* boxes, float* sbox, float (*sh)[4]) {
+    static_assert(PLAN_BBOX_BLOCKS == 256, "one partial per thread");
+    const float4 p = boxes[threadIdx.x];
+    float v[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (k & 2) ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[wave][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float r = sh[0][k];
+        for (int w = 1; w < 4; ++w) r = (k & 2) ? fmaxf(r, sh[w][k]) : fminf(r, sh[w][k]);
+        sbox[k] = r;
+    }
+}
+
+// Launch 2: cell key of every Gaussian / point and its rank inside the cell, with ONE returning
+// atomic per run of equal keys in a wave (points of a regular grid arrive in runs that share a
+// cell): the run leader adds the run length to the cell counter, the others take consecutive
+// ranks behind it.  run_* split the step so that several independent atomics are in flight.
+struct Run { int start; uint32_t len; bool leader; };
+__device__ __forceinline__ Run run_of(uint32_t k, int lane) {
+    const uint32_t prev = __shfl_up(k, 1);
+    Run r;
+    r.leader = lane == 0 || k != prev;
+    const uint64_t lm = __ballot(r.leader);
+    const uint64_t upto = (2ull << lane) - 1ull;          // bits 0..lane (lane 63: all ones)
+    r.start = 63 - __builtin_clzll(lm & upto);
+    const uint64_t above = lm & ~upto;
+    r.len = (uint32_t)((above ? __builtin_ctzll(above) : 64) - lane);   // meaningful for leaders
+    return r;
+}
+
+__global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
+    __shared__ float shb[4][4];
+    const int lane = threadIdx.x & 63;
+    // Every dependent memory round trip costs 2-4 us in this kernel (in-kernel stamps): issue the
+    // workgroup's own loads first, so they fly while the bounding-box partials are reduced.
+    const uint32_t gblocks = a.do_plan ? (a.N + 255) / 256 : 0;
+    const bool gpart = blockIdx.x < gblocks;
+    float gm[2] = {0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f};
+    float2 pt[4];
+    const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
+    if (gpart) {
+        if (gi < a.N) {
+            gm[0] = a.means[2 * gi]; gm[1] = a.means[2 * gi + 1];
+            gc[0] = a.conics[3 * gi]; gc[1] = a.conics[3 * gi + 1]; gc[2] = a.conics[3 * gi + 2];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            pt[k] = i < a.M ? ((const float2*)a.samples)[i] : make_float2(0.f, 0.f);
+        }
+    }
+    float sbox[4];
+    if (a.do_samples) {
+        reduce_boxes(a.sboxes, sbox, shb);
+    } else {      // the samples workspace is complete: its box is in its header
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sbox[k] = a.sparams->box[k];
+    }
+    const GaussGrid g = gauss_grid(sbox, a.G0);
+    const SampleGrid sg = sample_grid(sbox, a.M, a.scells_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.do_samples) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.sparams->box[k] = sbox[k];
+            a.sparams->sg = sg;
+            a.sparams->scan_error = 0;
+        }
+        if (a.do_plan) {
+            a.params->gg = g;
+            a.params->scan_error = 0;
+#pragma unroll
+            for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
+        }
+    }
+    // Gaussian workgroups first, sample workgroups after them: the two halves are independent
+    // latency chains (load -> returning atomic -> store) and run concurrently on different CUs
+    if (gpart) {                        // block-uniform: whole waves enter
+        const uint32_t i = gi;
+        const bool valid = i < a.N;
+        uint32_t key = 0xffffffffu;
+        int l = 0;
+        if (valid) {
+            const float mx = gm[0], my = gm[1];
+            const float ca = gc[0], cb = gc[1], cc = gc[2];
+            // half extents of the q <= q_max ellipse: sqrt(q_max * Sigma_xx), Sigma = C^-1
+            const float det = ca * cc - cb * cb;
+            const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
+            float s = g.s0;
+            while (l < a.L - 1 && !(R <= s)) { ++l; s *= 2.f; }
+            const int G = a.G0 >> l;
+            const float inv_s = 1.f / s;
+            const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
+            const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
+            key = a.level_off[l] + ((uint32_t)(cy * G + cx) << level_shift((uint32_t)(G * G)));
+        }
+        const Run r = run_of(key, lane);
+        uint32_t base = 0;
+        if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
+        base = __shfl(base, r.start);
+        if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
+    } else {
+        // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
+        uint32_t id[4], base[4];
+        Run r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            id[k] = 0xffffffffu;
+            if (i < a.M) {
+                const float2 p = pt[k];
+                const int cx = (int)clampf((p.x - sg.ox) * sg.inv_w, 0.f, (float)(sg.nx - 1));
+                const int cy = (int)clampf((p.y - sg.oy) * sg.inv_w, 0.f, (float)(sg.ny - 1));
+                id[k] = sample_cell_id(cx, cy, sg.nx);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = run_of(id[k], lane);
+            base[k] = 0;
+            if (r[k].leader && id[k] != 0xffffffffu)
+                base[k] = atomicAdd(&a.scounts[id[k]], r[k].len);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            const uint32_t b = __shfl(base[k], r[k].start);
+            if (i < a.M) a.skey[i] = make_uint2(id[k], b + (uint32_t)(lane - r[k].start));
+        }
+    }
+}
+
+// Launch 3: exclusive scan counts -> starts in ONE launch, for the Gaussian cells and (when the
+// samples are built alongside) the sample cells: two independent segments.  A workgroup scans
+// PLAN_SCAN_BLOCK counters (one coalesced uint4 per thread), publishes its total as one 8-byte
+// {flag, total} granule (single agent-scope store: data and flag travel together, no fence
+// needed) and sums the granules of the workgroups before it; nobody waits on a later workgroup.
+// The wait on a predecessor is bounded: in-order dispatch (what the hardware does) makes it
+// short, and should a predecessor ever fail to arrive the kernel ends with `scan_error` set in
+// the workspace header instead of hanging the device.
+constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 22;
+__global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
+    __shared__ uint32_t sh[4];
+    __shared__ uint32_t sh2[4];
+    const uint32_t nb0 = a.do_plan ? a.scan_blocks : 0;
+    const bool seg0 = blockIdx.x < nb0;
+    const uint32_t b = seg0 ? blockIdx.x : blockIdx.x - nb0;
+    const uint32_t* counts = seg0 ? a.counts : a.scounts;
+    unsigned long long* agg = seg0 ? a.agg : a.sagg;
+    uint32_t* starts = seg0 ? a.starts : a.sstarts;
+    uint32_t* err = seg0 ? &a.params->scan_error : &a.sparams->scan_error;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = b * 256 + threadIdx.x;          // uint4 index
+    const uint4 v = ((const uint4*)counts)[q];
+    const uint32_t s = v.x + v.y + v.z + v.w;
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&agg[b], (1ull << 32) | (sh[0] + sh[1] + sh[2] + sh[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t pre = 0;
+    for (uint32_t t = threadIdx.x; t < b; t += 256) {
+        unsigned long long x;
+        uint32_t spins = 0;
+        do {
+            x = __hip_atomic_load(&agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(x >> 32)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SCAN_SPIN_LIMIT) { atomicOr(err, 1u); break; }
+            }
+        } while (!(x >> 32));
+        pre += (uint32_t)x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    if (lane == 0) sh2[wave] = pre;
+    __syncthreads();
+    uint32_t run = inc - s + sh2[0] + sh2[1] + sh2[2] + sh2[3];
+    for (int w = 0; w < wave; ++w) run += sh[w];
+    uint4 o4;
+    o4.x = run; o4.y = run + v.x; o4.z = o4.y + v.y; o4.w = o4.z + v.z;
+    ((uint4*)starts)[q] = o4;      // counters beyond the last cell are zero: starts[ncells] = total
+}
+
+// Launch 4: scatter into sorted order (no atomics: position = cell start + rank) and publish the
+// level mask.
+__global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
+    const uint32_t gblocks = a.do_plan ? (a.N + 255) / 256 : 0;
+    const bool gpart = blockIdx.x < gblocks;
+    const uint32_t i = (gpart ? blockIdx.x : blockIdx.x - gblocks) * 256 + threadIdx.x;
+    if (a.do_plan && blockIdx.x == 0 && threadIdx.x < 64) {
+        // level l holds a Gaussian iff its cells' scanned range is not empty (no atomics, no scratch)
+        const int l = (int)threadIdx.x;
+        const int lc = l < a.L ? l : 0;
+        const bool occ = l < a.L && a.starts[a.level_off[lc + 1]] != a.starts[a.level_off[lc]];
+        const uint64_t m = __ballot(occ);
+        if (threadIdx.x == 0) a.params->level_mask = (uint32_t)m;
+    }
+    if (gpart && i < a.N) {
+        const uint2 kr = a.gkey[i];
+        const uint32_t pos = a.starts[kr.x] + kr.y;
+        float v[2] = {0.f, 0.f};
+        for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
+        // {mux, muy, a, b}, {b, c, v0, v1}
+        a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
+        a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 1], a.conics[3 * i + 2], v[0], v[1]);
+        {   // bounding box of the q <= q_max ellipse: half extents sqrt(q_max Sigma_xx), sqrt(q_max Sigma_yy)
+            const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
+            const float k = a.q_max / (ca * cc - cb * cb);
+            float hx = sqrtf(k * cc), hy = sqrtf(k * ca);
+            if (!(hx < 3.0e38f)) hx = 3.0e38f;      // NaN / inf (degenerate conic): always a candidate
+            if (!(hy < 3.0e38f)) hy = 3.0e38f;
+            a.gbox[pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], hx * 1.0001f, hy * 1.0001f);
+        }
+        a.g2o[pos] = i;
+        // the backward's scratch starts zeroed (and plan_unpermute_kernel re-zeroes what it
+        // reads), so the backward needs no memset launch
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a.gacc[(size_t)k * a.N + pos] = 0.f;
+    }
+    if (!gpart && i < a.M) {
+        const uint2 kr = a.skey[i];
+        const float2 p = ((const float2*)a.samples)[i];
+        SPoint sp;
+        sp.x = p.x; sp.y = p.y; sp.m = i;
+        a.spts[a.sstarts[kr.x] + kr.y] = sp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// candidate test: does the ellipse q <= q_max of a Gaussian reach the rectangle [x0,x1]x[y0,y1]?
+// q is convex with its minimum at the centre, so the minimum over the rectangle lies on the
+// edge(s) facing the centre; each facing edge is minimised in closed form.  Comparisons are
+// written so that NaN (degenerate conic) accepts.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ellipse_reaches_rect(float4 A, float cc, float x0, float y0, float x1, float y1,
+                                                     float q_max) {
+    const float l = x0 - A.x, r = x1 - A.x, bt = y0 - A.y, tp = y1 - A.y;
+    const float a = A.z, b = A.w;
+    const float xe = clampf(0.f, l, r), ye = clampf(0.f, bt, tp);
+    const float ys = clampf(-b * xe * __builtin_amdgcn_rcpf(cc), bt, tp);
+    const float xs = clampf(-b * ye * __builtin_amdgcn_rcpf(a), l, r);
+    const float q1 = a * xe * xe + (2.f * b * xe + cc * ys) * ys;
+    const float q2 = cc * ye * ye + (2.f * b * ye + a * xs) * xs;
+    return !(fminf(q1, q2) > q_max);
+}
+
+// Workgroups are dispatched round-robin over the 8 XCDs (workgroup i runs on XCD i % 8) and every
+// XCD has its own L2.  Tiles follow the domain block row by block row, so inside every group of
+// 8 * PIGS_XCD_CHUNK consecutive workgroups XCD x takes the x-th contiguous run of PIGS_XCD_CHUNK:
+// each L2 then holds the Gaussian records and lists of a strip of the domain instead of all of
+// them, while the launch still sweeps the domain once from top to bottom.  Bijective for any grid
+// size (blocks behind the last whole group keep their index).  0 = no remapping.
+#ifndef PIGS_XCD_CHUNK
+#define PIGS_XCD_CHUNK 256
+#endif
+__device__ __forceinline__ uint32_t xcd_block() {
+#if PIGS_XCD_CHUNK > 0
+    constexpr uint32_t GROUP = 8u * PIGS_XCD_CHUNK;
+    const uint32_t b = blockIdx.x, g = b / GROUP, r = b % GROUP;
+    if ((g + 1) * GROUP > gridDim.x) return b;
+    return g * GROUP + (r & 7u) * PIGS_XCD_CHUNK + (r >> 3);
+#else
+    return blockIdx.x;
+#endif
+}
+
+// Bounding boxes with the DPP modifier fused into the min / max (hipcc emits v_mov_dpp + a
+// canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  The four
+// reductions are independent chains and are interleaved step by step, so the two wait states a
+// DPP read needs after the VALU write of its source are filled by the other three chains: one
+// s_nop at the head instead of one per step (an s_nop costs an issue slot like a VALU
+// instruction).  row_box_dpp leaves in every lane the box of the lane's own 16-lane row;
+// wave_box_dpp continues from there to the box of the wave, broadcast from lane 63.
+#define PIGS_BOX_STEP(MOD)                                \
+    "v_min_f32_dpp %0, %0, %0 " MOD " bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %1, %1, %1 " MOD " bank_mask:0xf\n\t" \
+    "v_min_f32_dpp %2, %2, %2 " MOD " bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %3, %3, %3 " MOD " bank_mask:0xf\n\t"
+__device__ __forceinline__ void row_box_dpp(float& x0, float& x1, float& y0, float& y1) {
+    asm volatile("s_nop 1\n\t"
+                 PIGS_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
+                 PIGS_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
+                 PIGS_BOX_STEP("row_half_mirror row_mask:0xf")
+                 PIGS_BOX_STEP("row_mirror row_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+}
+__device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, float& y0, float& y1) {
+    asm volatile("s_nop 1\n\t"
+                 PIGS_BOX_STEP("row_bcast:15 row_mask:0xa")
+                 PIGS_BOX_STEP("row_bcast:31 row_mask:0xc")
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+    x0 = readlane_f(x0, 63); x1 = readlane_f(x1, 63); y0 = readlane_f(y0, 63); y1 = readlane_f(y1, 63);
+}
+
+// ------------------------------------------------------------------------------------------
+// Traversal of the Gaussian grid for one rectangle (used by the list build only):
+//   1. lane = level: rectangle of cells within one cell of the box; its rows scattered into an
+//      LDS table, then ONE gather fetches every row's record range  -> `rows(nrow, jb, len)`
+//   2. two-stage culling.  Stage 1: the rows' ranges are walked in wave-uniform order,
+//      PIGS_TRAV_STEPS steps (64 candidates each) at a time -- their 16-byte {centre, half
+//      extents} records are all in flight together (every dependent round trip costs
+//      microseconds here) -- and tested box against box (8 instructions); survivors' indices go
+//      to an LDS list.  Stage 2: survivors' full records are gathered 64 at a time, tested exactly
+//      (ellipse against box) and handed to `batch(A, B, mask, j)`: this lane's record and its
+//      sorted Gaussian index, `mask` = the lanes that hold an accepted one.
+// ------------------------------------------------------------------------------------------
+constexpr int CCAP = 256;   // bbox-accepted candidate indices buffered per wave before the exact test
+static_assert(CCAP >= 128, "a batch of two steps adds up to 128 candidates behind a flush");
+struct TravLds {
+    uint32_t row_a0[64];
+    uint32_t row_a1[64];
+    uint32_t cand[CCAP + 64];
+};
+
+template <typename Rows, typename Batch>
+__device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg, uint32_t level_mask, uint32_t loff,
+                                         float bx0, float by0, float bx1, float by1, int lane, TravLds& lds,
+                                         bool walk, Rows&& rows, Batch&& batch) {
+    const bool occ = lane < pv.L && (level_mask >> lane & 1u);
+    const int sh = lane < pv.L ? lane : 0;
+    const int G = pv.G0 >> sh;
+    const float inv_s = gg.inv_s0 * __builtin_amdgcn_ldexpf(1.f, -sh);
+    const float gmax = (float)(G - 1);
+    const int cx0 = (int)clampf(floorf((bx0 - gg.ox) * inv_s) - 1.f, 0.f, gmax);
+    const int cx1 = (int)clampf(floorf((bx1 - gg.ox) * inv_s) + 1.f, 0.f, gmax);
+    const int cy0 = (int)clampf(floorf((by0 - gg.oy) * inv_s) - 1.f, 0.f, gmax);
+    const int cy1 = (int)clampf(floorf((by1 - gg.oy) * inv_s) + 1.f, 0.f, gmax);
+    const int nr = occ ? cy1 - cy0 + 1 : 0;
+    const int csh = level_shift((uint32_t)(G * G));      // the level's counter spacing
+    int inc = nr;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {           // levels live in lanes 0..11
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    const int cum = inc - nr;
+    const int R = __builtin_amdgcn_readlane(inc, 15);
+
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        for (int k = 0; k < nr; ++k) {
+            const int r = cum + k - r0;
+            if (r >= 0 && r < 64) {
+                const uint32_t row = (uint32_t)((cy0 + k) * G);
+                lds.row_a0[r] = loff + ((row + (uint32_t)cx0) << csh);
+                lds.row_a1[r] = loff + ((row + (uint32_t)cx1 + 1u) << csh);
+            }
+        }
+        wave_lds_fence();
+        const int nrow = R - r0 < 64 ? R - r0 : 64;
+        uint32_t jbv = 0, lenv = 0;
+        if (lane < nrow) {
+            jbv = pv.starts[lds.row_a0[lane]];
+            lenv = pv.starts[lds.row_a1[lane]] - jbv;
+        }
+        wave_lds_fence();
+        rows(nrow, jbv, lenv);
+        if (!walk) continue;
+        int r = -1;
+        uint32_t j0 = 0, je = 0;
+        auto advance = [&]() -> bool {
+            j0 += 64;
+            while (j0 >= je) {
+                if (++r >= nrow) return false;
+                j0 = (uint32_t)__builtin_amdgcn_readlane((int)jbv, r);
+                je = j0 + (uint32_t)__builtin_amdgcn_readlane((int)lenv, r);
+            }
+            return true;
+        };
+        int cn = 0;
+        auto exact_stage = [&]() {
+            wave_lds_fence();
+            for (int b0 = 0; b0 < cn; b0 += 128) {
+                // two gathers in flight
+                const bool in0 = b0 + lane < cn, in1 = b0 + 64 + lane < cn;
+                const uint32_t i0 = in0 ? lds.cand[b0 + lane] : lds.cand[0];
+                const uint32_t i1 = in1 ? lds.cand[b0 + 64 + lane] : lds.cand[0];
+                const float4 A0 = pv.rec[2 * i0], B0 = pv.rec[2 * i0 + 1];
+                float4 A1 = A0, B1 = B0;
+                if (b0 + 64 < cn) { A1 = pv.rec[2 * i1]; B1 = pv.rec[2 * i1 + 1]; }
+                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.y, bx0, by0, bx1, by1, pv.q_max));
+                if (m0) batch(A0, B0, m0, i0);
+                if (b0 + 64 < cn) {
+                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.y, bx0, by0, bx1, by1, pv.q_max));
+                    if (m1) batch(A1, B1, m1, i1);
+                }
+            }
+            wave_lds_fence();
+            cn = 0;
+        };
+        bool have = advance();
+        while (have) {
+            uint32_t sj[PIGS_TRAV_STEPS], se[PIGS_TRAV_STEPS];
+            float4 T[PIGS_TRAV_STEPS];
+            int ns = 0;
+#pragma unroll
+            for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
+                sj[u] = j0; se[u] = je;
+                if (have) {
+                    ns = u + 1;
+                    const uint32_t j = j0 + lane < je ? j0 + lane : j0;
+                    T[u] = pv.gbox[j];
+                    have = advance();
+                } else {
+                    se[u] = sj[u];          // empty step
+                    T[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
+                if (u < ns) {
+                    const float ex = fmaxf(fmaxf(bx0 - T[u].x, T[u].x - bx1), 0.f);
+                    const float ey = fmaxf(fmaxf(by0 - T[u].y, T[u].y - by1), 0.f);
+                    const bool ok = (sj[u] + lane < se[u]) && ex <= T[u].z && ey <= T[u].w;
+                    const uint64_t mask = __ballot(ok);
+                    if (mask) {
+                        if (ok) lds.cand[cn + lanes_below(mask)] = sj[u] + lane;
+                        cn += __builtin_popcountll(mask);
+                        if (cn > CCAP - 64) exact_stage();
+                    }
+                }
+            }
+        }
+        exact_stage();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch 5 of a plan build: the tile lists.  One wave = one tile: the boxes of its four 16-point
+// groups (DPP row reductions) and of the tile, one traversal against the tile's box, and for
+// every accepted Gaussian the four group tests; entries with an empty mask (the ellipse reaches
+// the tile's box but none of its groups') are dropped.
+// ------------------------------------------------------------------------------------------
+struct ListArgs {
+    PlanView pv;
+    SamplesView sv;
+    uint32_t* hdr;
+    uint32_t* lists;
+};
+
+__global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
+    __shared__ TravLds lds_all[4];
+    const PlanView& pv = a.pv;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
+    if (tile >= a.sv.ntiles) return;
+    TravLds& lds = lds_all[wave];
+    const GaussGrid gg = pv.params->gg;
+    const uint32_t level_mask = pv.params->level_mask;
+    const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
+    const float INF = __builtin_huge_valf();
+    const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
+    const bool valid = m < a.sv.M;
+    SPoint sp = {0.f, 0.f, 0u};
+    if (valid) sp = a.sv.spts[m];
+    float x0 = valid ? sp.x : INF, x1 = valid ? sp.x : -INF, y0 = valid ? sp.y : INF, y1 = valid ? sp.y : -INF;
+    row_box_dpp(x0, x1, y0, y1);
+    float gx0[4], gx1[4], gy0[4], gy1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        gx0[g] = readlane_f(x0, 16 * g); gx1[g] = readlane_f(x1, 16 * g);
+        gy0[g] = readlane_f(y0, 16 * g); gy1[g] = readlane_f(y1, 16 * g);
+    }
+    wave_box_from_rows_dpp(x0, x1, y0, y1);
+    const float bx0 = x0, bx1 = x1, by0 = y0, by1 = y1;
+
+    uint32_t* slab = a.lists + (size_t)tile * pv.list_cap;
+    uint32_t n = 0;
+    bool overflow = false;
+    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds, true,
+             [](int, uint32_t, uint32_t) {},
+             [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
+        uint32_t gm = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // a group without a point (the ragged last tile) has an inverted box: never needed
+            if (gx0[g] <= gx1[g] && ellipse_reaches_rect(A, B.y, gx0[g], gy0[g], gx1[g], gy1[g], pv.q_max)) gm |= 1u << g;
+        }
+        const bool keep = (mask >> lane & 1ull) && gm != 0u;
+        const uint64_t km = __ballot(keep);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
+        if (n + cnt <= pv.list_cap) {
+            if (keep) slab[n + (uint32_t)lanes_below(km)] = j | (gm << LIST_IDX_BITS);
+        } else {
+            overflow = true;
+        }
+        n += cnt;
+    });
+    if (!overflow) {
+        if (lane == 0) a.hdr[tile] = n | (TILE_MODE_LIST << TILE_MODE_SHIFT);
+        return;
+    }
+    // The list does not fit: keep the grid's record ranges around the tile instead (pairs {first,
+    // length}); when even those do not fit, the single range of all Gaussians.
+    uint32_t nr = 0;
+    bool fits = true;
+    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds, false,
+             [&](int nrow, uint32_t jb, uint32_t len) {
+        const bool keep = lane < nrow && len > 0;
+        const uint64_t km = __ballot(keep);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
+        if (2 * (nr + cnt) <= pv.list_cap) {
+            if (keep) {
+                const uint32_t p = 2 * (nr + (uint32_t)lanes_below(km));
+                slab[p] = jb; slab[p + 1] = len;
+            }
+        } else {
+            fits = false;
+        }
+        nr += cnt;
+    },
+             [](const float4, const float4, uint64_t, uint32_t) {});
+    if (!fits) {
+        if (lane == 0) { slab[0] = 0; slab[1] = pv.N; }
+        nr = 1;
+    }
+    if (lane == 0) a.hdr[tile] = nr | (TILE_MODE_RANGES << TILE_MODE_SHIFT);
+}
+
+// ------------------------------------------------------------------------------------------
+// Sampling kernels.  One wave = one tile; a step = 64 list entries (lane = entry): their records
+// go to the wave's LDS (slot = lane), their group masks are split into four per-row index lists
+// holding LDS byte offsets, padded with the offset of an all-zero record to the longest of the
+// four; then the rows are evaluated together, every row on its own list.
+// ------------------------------------------------------------------------------------------
+constexpr int LIST_PAD = 2 * PIGS_FWD_UNROLL > 8 ? 2 * PIGS_FWD_UNROLL : 8;
+struct TileLds {
+    float4 rec[TILE_POINTS + 1][2];            // slot 64: the all-zero record (v = 0: contributes nothing)
+    uint32_t list[4][TILE_POINTS + LIST_PAD];  // byte offsets into rec
+};
+constexpr uint32_t ZERO_REC_OFF = TILE_POINTS * 32u;
+
+// splits the step's masks; returns the padded row count (a multiple of UNROLL)
+template <int UNROLL>
+__device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane) {
+    int cnt[4], rows = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const bool bit = gm >> g & 1u;
+        const uint64_t m = __ballot(bit);
+        if (bit) lds.list[g][lanes_below(m)] = (uint32_t)lane * 32u;
+        cnt[g] = __builtin_popcountll(m);
+        rows = cnt[g] > rows ? cnt[g] : rows;
+    }
+    rows = (rows + UNROLL - 1) / UNROLL * UNROLL;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (cnt[g] + lane < rows + UNROLL) lds.list[g][cnt[g] + lane] = ZERO_REC_OFF;   // + UNROLL: the prefetch
+    return rows;
+}
+
+struct Rec {
+    float mu[2], con[3], v[2];
+};
+__device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
+    Rec r;
+    r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.y;
+    r.v[0] = B.z; r.v[1] = B.w;
+    return r;
+}
+
+template <int C, int MASK>
+__device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const TileLds& lds, int rows, int lane) {
+    constexpr int U = PIGS_FWD_UNROLL;       // rows per iteration (independent chains for ILP)
+    if (rows == 0) return;
+    const char* base = (const char*)&lds.rec[0][0];
+    const uint32_t* lst = lds.list[lane >> 4];
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t off = lst[u];
+        a[u] = *(const float4*)(base + off);
+        b[u] = *(const float4*)(base + off + 16);
+    }
+    for (int k = 0; k < rows; k += U) {
+        float4 na[U], nb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t off = lst[k + U + u];
+            na[u] = *(const float4*)(base + off);
+            nb[u] = *(const float4*)(base + off + 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Rec r = make_rec(a[u], b[u]);
+            fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = na[u]; b[u] = nb[u]; }
+    }
+}
+
+// Walks a tile's list (or its ranges): `step(idx, gm, have)` for every 64 entries.
+template <typename Step>
+__device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step) {
+    const uint32_t hdr = pv.hdr[tile];
+    const uint32_t count = hdr & TILE_COUNT_MASK;
+    const uint32_t* slab = pv.lists + (size_t)tile * pv.list_cap;
+    if ((hdr >> TILE_MODE_SHIFT) == TILE_MODE_LIST) {
+        for (uint32_t e0 = 0; e0 < count; e0 += 64) {
+            const bool have = e0 + (uint32_t)lane < count;
+            const uint32_t e = have ? slab[e0 + lane] : 0u;
+            step(e & LIST_IDX_MASK, e >> LIST_IDX_BITS, have);
+        }
+    } else {
+        for (uint32_t r = 0; r < count; ++r) {
+            const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
+            for (uint32_t o = 0; o < len; o += 64) {
+                const bool have = o + (uint32_t)lane < len;
+                step(have ? j0 + o + (uint32_t)lane : j0, have ? 0xFu : 0u, have);
+            }
+        }
+    }
+}
+
+// register budget: 8 waves/SIMD (64 VGPRs) for the narrow variants, fewer waves for the wide ones
+// (c = 2 with orders up to 3: 12-20 accumulators) so that they do not spill
+template <int C, int MASK>
+constexpr int fwd_waves() {
+    constexpr int n = FwdLayout<2, C, MASK>::N;
+    return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1)) ? PIGS_FWD_WAVES : 6;
+}
+template <int C, int MASK>
+__global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kernel(
+    PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
+    float* __restrict__ o3) {
+    using L = FwdLayout<2, C, MASK>;
+    __shared__ TileLds lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
+    if (tile >= sv.ntiles) return;
+    TileLds& lds = lds_all[wave];
+    const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
+    const bool valid = m < sv.M;
+    const SPoint sp = sv.spts[valid ? m : sv.M - 1];      // lanes behind the last point repeat it (never stored)
+    const float s[2] = {sp.x, sp.y};
+    if (lane < 2) lds.rec[TILE_POINTS][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
+    for_each_step(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool) {
+        const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
+        wave_lds_fence();                      // the previous step's reads are behind us
+        lds.rec[lane][0] = A;
+        lds.rec[lane][1] = B;
+        const int rows = split_step<PIGS_FWD_UNROLL>(lds, gm, lane);
+        wave_lds_fence();
+        evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
+    });
+    if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward: the same tile / list / LDS structure.  Every (row, Gaussian) pair of a step yields
+// NV = 5 + c per-lane contributions that must be summed over the row's 16 points; the sums of the
+// (up to four) rows that work on the same Gaussian meet in an LDS table indexed by the entry's
+// slot (ds_add_f32), which is flushed once per step with one atomic per entry and value into
+// gacc[k][j] (entries follow the sorted order, so consecutive lanes hit near-consecutive
+// addresses); plan_unpermute_kernel writes the caller's layout.
+// ------------------------------------------------------------------------------------------
+struct TileLdsBwd {
+    TileLds t;
+    float sums[TILE_POINTS + 1][8];   // per-slot reduced contributions; row 64 collects the padding rows
+};
+
+// sum over the 16 lanes of a row, in every lane of it, for G values at once: the chains are
+// independent and interleaved so that one s_nop covers the DPP wait states of all of them
+#define PIGS_ROW1(MOD, R) "v_add_f32_dpp " R ", " R ", " R " " MOD " row_mask:0xf bank_mask:0xf\n\t"
+#define PIGS_ROW3(MOD) PIGS_ROW1(MOD, "%0") PIGS_ROW1(MOD, "%1") PIGS_ROW1(MOD, "%2")
+#define PIGS_ROW4(MOD) PIGS_ROW3(MOD) PIGS_ROW1(MOD, "%3")
+template <int G>
+__device__ __forceinline__ void row_sum_group(float* y) {
+    static_assert(G == 3 || G == 4, "groups of three or four");
+    if constexpr (G == 3)
+        asm volatile("s_nop 1\n\t" PIGS_ROW3("quad_perm:[1,0,3,2]") PIGS_ROW3("quad_perm:[2,3,0,1]")
+                     PIGS_ROW3("row_half_mirror") PIGS_ROW3("row_mirror") "s_nop 1"
+                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]));
+    else
+        asm volatile("s_nop 1\n\t" PIGS_ROW4("quad_perm:[1,0,3,2]") PIGS_ROW4("quad_perm:[2,3,0,1]")
+                     PIGS_ROW4("row_half_mirror") PIGS_ROW4("row_mirror") "s_nop 1"
+                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+
+template <int C, int MASK>
+__device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 2, C, MASK>& G, TileLdsBwd& lds,
+                                              int rows, int lane) {
+    using BL = BwdLayout<2, C>;
+    constexpr int NV = BL::N;
+    const char* base = (const char*)&lds.t.rec[0][0];
+    const uint32_t* lst = lds.t.list[lane >> 4];
+    const bool leader = (lane & 15) == 0;
+    for (int k = 0; k < rows; ++k) {
+        const uint32_t off = lst[k];
+        const Rec r = make_rec(*(const float4*)(base + off), *(const float4*)(base + off + 16));
+        float part[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) part[q] = 0.f;
+        bwd_accumulate<float, 2, C, MASK, (MASK & ORD3) != 0>(part, s, r.mu, r.con, r.v, G);
+        row_sum_group<3>(part);
+        if constexpr (NV == 6) row_sum_group<3>(part + 3);
+        else row_sum_group<4>(part + 3);
+        if (leader) {
+            float* dst = lds.sums[off >> 5];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) __hip_atomic_fetch_add(&dst[q], part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+template <int C, int MASK>
+constexpr int bwd_waves() {      // the widest gradient sets get 3 waves (168 VGPRs): no spills
+    return ((C == 2 && (MASK == 7 || MASK == 8 || MASK == 15)) || (C == 1 && MASK == 15)) ? 3 : PIGS_BWD_WAVES;
+}
+template <int C, int MASK>
+__global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
+    PlanView pv, SamplesView sv, const float* __restrict__ G0p, const float* __restrict__ G1p,
+    const float* __restrict__ G2p, const float* __restrict__ G3p) {
+    using BL = BwdLayout<2, C>;
+    constexpr int NV = BL::N;
+    __shared__ TileLdsBwd lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
+    if (tile >= sv.ntiles) return;
+    TileLdsBwd& lds = lds_all[wave];
+    const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
+    const bool valid = m < sv.M;
+    const SPoint sp = sv.spts[valid ? m : sv.M - 1];
+    const float s[2] = {sp.x, sp.y};
+    Gsym<float, 2, C, MASK> G;
+    G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
+    if (!valid) {               // lanes behind the last point contribute nothing
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            G.g0[ch] = 0.f;
+            G.g1[0][ch] = G.g1[1][ch] = 0.f;
+            G.g2[0][ch] = G.g2[1][ch] = G.g2[2][ch] = 0.f;
+            G.g3[0][ch] = G.g3[1][ch] = G.g3[2][ch] = G.g3[3][ch] = 0.f;
+        }
+    }
+    if (lane < 2) lds.t.rec[TILE_POINTS][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds.sums[lane][q] = 0.f;
+    for_each_step(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
+        const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
+        wave_lds_fence();
+        lds.t.rec[lane][0] = A;
+        lds.t.rec[lane][1] = B;
+        const int rows = split_step<1>(lds.t, gm, lane);
+        wave_lds_fence();
+        backward_rows<C, MASK>(s, G, lds, rows, lane);
+        wave_lds_fence();
+        if (have && gm != 0u) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], lds.sums[lane][q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) lds.sums[lane][q] = 0.f;
+    });
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void plan_unpermute_kernel(PlanView pv, float* __restrict__ g_means,
+                                                             float* __restrict__ g_conics,
+                                                             float* __restrict__ g_values) {
+    using BL = BwdLayout<2, C>;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= pv.N) return;
+    const uint32_t n = pv.g2o[j];
+    float v[BL::N];
+#pragma unroll
+    for (int k = 0; k < BL::N; ++k) {
+        v[k] = pv.gacc[(size_t)k * pv.N + j];
+        pv.gacc[(size_t)k * pv.N + j] = 0.f;       // leave the scratch zeroed for the next backward
+    }
+    g_means[2 * n] = v[BL::MU + 0];
+    g_means[2 * n + 1] = v[BL::MU + 1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_conics[3 * n + k] = v[BL::CON + k];
+#pragma unroll
+    for (int k = 0; k < C; ++k) g_values[(size_t)C * n + k] = v[BL::VAL + k];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static bool samples_supported(int64_t M) { return M >= 1 && M < (1LL << 31) - 64; }
+static bool plan_supported(int64_t N, int64_t M, int c) {
+    return samples_supported(M) && N >= 1 && c >= 1 && c <= 2 && N < (1LL << LIST_IDX_BITS);
+}
+
+static SamplesView make_samples_view(const SamplesLayout& p, const void* sws) {
+    const char* b = (const char*)sws;
+    SamplesView v{};
+    v.params = (const SampleParams*)(b + p.off_params);
+    v.spts = (const SPoint*)(b + p.off_spts);
+    v.M = (uint32_t)p.M;
+    v.ntiles = p.ntiles;
+    return v;
+}
+
+static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
+    char* b = (char*)ws;
+    PlanView v{};
+    v.params = (const PlanParams*)(b + p.off_params);
+    v.starts = (const uint32_t*)(b + p.off_starts);
+    v.rec = (const float4*)(b + p.off_rec);
+    v.gbox = (const float4*)(b + p.off_box);
+    v.g2o = (const uint32_t*)(b + p.off_g2o);
+    v.hdr = (const uint32_t*)(b + p.off_hdr);
+    v.lists = (const uint32_t*)(b + p.off_lists);
+    v.N = (uint32_t)p.N;
+    v.list_cap = p.list_cap;
+    v.G0 = p.G0; v.L = p.L;
+    for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) v.level_off[l] = p.level_off[l];
+    v.q_max = q_max;
+    v.gacc = (float*)(b + p.off_gacc);
+    return v;
+}
+
+size_t samples_error_offset() { return offsetof(SampleParams, scan_error); }
+size_t plan_error_offset() { return offsetof(PlanParams, scan_error); }
+
+size_t samples_workspace_bytes(int64_t M) {
+    if (!samples_supported(M)) return 0;
+    return make_samples_layout(M).total_bytes;
+}
+
+size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
+    if (!plan_supported(N, M, c)) return 0;
+    return make_plan_layout(N, M, c).total_bytes;
+}
+
+static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, const void* samples) {
+    char* b = (char*)sws;
+    a.sparams = (SampleParams*)(b + s.off_params);
+    a.sboxes = (float4*)(b + s.off_boxes);
+    a.scounts = (uint32_t*)(b + s.off_counts);
+    a.sagg = (unsigned long long*)(b + s.off_agg);
+    a.sstarts = (uint32_t*)(b + s.off_starts);
+    a.skey = (uint2*)(b + s.off_skey);
+    a.spts = (SPoint*)(b + s.off_spts);
+    a.samples = (const float*)samples;
+    a.M = (uint32_t)s.M;
+    a.scells_cap = s.scells_cap;
+    a.s_scan_blocks = s.scan_blocks;
+    a.s_zero_words = (uint32_t)((s.off_starts - s.off_counts) / 4);     // counters + aggregates
+}
+
+static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_max, const void* means,
+                           const void* conics, const void* values) {
+    char* b = (char*)ws;
+    a.params = (PlanParams*)(b + p.off_params);
+    a.counts = (uint32_t*)(b + p.off_counts);
+    a.agg = (unsigned long long*)(b + p.off_agg);
+    a.starts = (uint32_t*)(b + p.off_starts);
+    a.gkey = (uint2*)(b + p.off_gkey);
+    a.rec = (float4*)(b + p.off_rec);
+    a.gbox = (float4*)(b + p.off_box);
+    a.gacc = (float*)(b + p.off_gacc);
+    a.g2o = (uint32_t*)(b + p.off_g2o);
+    a.means = (const float*)means; a.conics = (const float*)conics; a.values = (const float*)values;
+    a.N = (uint32_t)p.N; a.c = p.c; a.G0 = p.G0; a.L = p.L;
+    a.scan_blocks = p.scan_blocks;
+    a.zero_words = (uint32_t)((p.off_starts - p.off_counts) / 4);
+    for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.level_off[l] = p.level_off[l];
+    a.q_max = q_max;
+}
+
+// The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
+// (build_plan) or both in the same four launches, then the tile lists.
+static int run_build(bool do_samples, bool do_plan, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
+                     int64_t M, int c, float q_max, const void* means, const void* conics, const void* values,
+                     const void* samples, hipStream_t stream) {
+    if (!samples_supported(M)) return PIGS_ERR_UNSUPPORTED;
+    const SamplesLayout s = make_samples_layout(M);
+    if (!sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
+    BuildArgs a{};
+    a.do_samples = do_samples; a.do_plan = do_plan;
+    fill_samples_args(a, s, sws, samples);
+    PlanLayout p{};
+    if (do_plan) {
+        if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
+        if (!(q_max > 0.f)) return PIGS_ERR_INVALID;
+        p = make_plan_layout(N, M, c);
+        if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
+        fill_plan_args(a, p, ws, q_max, means, conics, values);
+    }
+    clear_hip_error();
+    const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
+    if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 1023) / 1024) : 0u)), dim3(256), 0,
+                       stream, a);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? s.scan_blocks : 0u)),
+                       dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 255) / 256) : 0u)), dim3(256), 0,
+                       stream, a);
+    if (do_plan) {
+        ListArgs la{};
+        la.pv = make_view(p, ws, q_max);
+        la.sv = make_samples_view(s, sws);
+        la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
+        la.lists = (uint32_t*)((char*)ws + p.off_lists);
+        hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 3) / 4), dim3(256), 0, stream, la);
+    }
+    return launch_status();
+}
+
+int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream) {
+    return run_build(true, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, nullptr, nullptr, nullptr, samples, stream);
+}
+
+int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int build_samples, int64_t N, int64_t M, int c,
+               float q_max, const void* means, const void* conics, const void* values, const void* samples,
+               hipStream_t stream) {
+    return run_build(build_samples != 0, true, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, means, conics, values,
+                     samples, stream);
+}
+
+template <int C>
+static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, float* const* out, hipStream_t stream) {
+    const dim3 grid((sv.ntiles + 3) / 4), block(256);
+    clear_hip_error();
+#define PIGS_CASE(MK)                                                                                          \
+    case MK:                                                                                                   \
+        hipLaunchKernelGGL((tile_forward_kernel<C, MK>), grid, block, 0, stream, pv, sv, out[0], out[1], out[2], \
+                           out[3]);                                                                            \
+        break;
+    switch (mask) {
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
+        default: return PIGS_ERR_UNSUPPORTED;
+    }
+#undef PIGS_CASE
+    return launch_status();
+}
+
+template <int C>
+static int plan_backward_c(const PlanView& pv, const SamplesView& sv, int mask, const float* const* g, float* gm,
+                           float* gc, float* gv, hipStream_t stream) {
+    const dim3 grid((sv.ntiles + 3) / 4), block(256);
+    clear_hip_error();
+#define PIGS_CASE(MK)                                                                                             \
+    case MK:                                                                                                      \
+        hipLaunchKernelGGL((tile_backward_kernel<C, MK>), grid, block, 0, stream, pv, sv, g[0], g[1], g[2], g[3]); \
+        break;
+    switch (mask) {
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
+        default: return PIGS_ERR_UNSUPPORTED;
+    }
+#undef PIGS_CASE
+    hipLaunchKernelGGL((plan_unpermute_kernel<C>), dim3((pv.N + 255) / 256), dim3(256), 0, stream, pv, gm, gc, gv);
+    return launch_status();
+}
+
+int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
+                 float q_max, int mask, void* const* out, hipStream_t stream) {
+    if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
+    const PlanLayout p = make_plan_layout(N, M, c);
+    const SamplesLayout s = make_samples_layout(M);
+    if (!ws || ws_bytes < p.total_bytes || !sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
+    const PlanView pv = make_view(p, ws, q_max);
+    const SamplesView sv = make_samples_view(s, sws);
+    float* o[4];
+    for (int k = 0; k < 4; ++k) o[k] = mask_uses_slot(mask, k) ? (float*)out[k] : nullptr;
+    const int cm = covering_mask_of(mask);
+    switch (c) {
+        case 1: return plan_forward_c<1>(pv, sv, cm, o, stream);
+        case 2: return plan_forward_c<2>(pv, sv, cm, o, stream);
+    }
+    return PIGS_ERR_UNSUPPORTED;
+}
+
+int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
+                  float q_max, int mask, const void* const* gout, void* g_means, void* g_conics, void* g_values,
+                  hipStream_t stream) {
+    if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
+    const PlanLayout p = make_plan_layout(N, M, c);
+    const SamplesLayout s = make_samples_layout(M);
+    if (!ws || ws_bytes < p.total_bytes || !sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
+    const PlanView pv = make_view(p, ws, q_max);
+    const SamplesView sv = make_samples_view(s, sws);
+    const float* g[4];
+    for (int k = 0; k < 4; ++k) g[k] = mask_uses_slot(mask, k) ? (const float*)gout[k] : nullptr;
+    const int cm = covering_mask_of(mask);
+    switch (c) {
+        case 1: return plan_backward_c<1>(pv, sv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
+        case 2: return plan_backward_c<2>(pv, sv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
+    }
+    return PIGS_ERR_UNSUPPORTED;
+}
+
+}  // namespace pigs

@@ -73,14 +73,53 @@ def _slot2(ts):
     return ts[2] if ts[2] is not None else ts[TRACE]
 
 
+def _error_flag(workspace, offset):
+    return int(workspace[offset:offset + 4].view(torch.int32).item())
+
+
+class SamplePlan:
+    """The samples half of what ``preprocess`` builds (C ABI: pigs_samples_*): the sample points
+    sorted into 16-point cells.  A function of ``samples`` alone and immutable once built, so one
+    object serves every ``preprocess`` that is handed the same, unmodified samples tensor again --
+    the reference's roll-out (main_pn.py:317-324) and any fixed collocation grid."""
+
+    __slots__ = ("workspace", "M", "source", "version", "built")
+
+    def __init__(self, samples, source=None):
+        lib = _lib.load()
+        self.M = samples.shape[0]
+        nbytes = _WORKSPACE_BYTES.get(("s", self.M))
+        if nbytes is None:
+            nbytes = _WORKSPACE_BYTES[("s", self.M)] = lib.pigs_samples_workspace_bytes(self.M)
+        if nbytes == 0:
+            raise _lib.PigsError(f"binned path does not support M={self.M}")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=samples.device)
+        # what this plan was built from: the caller's tensor (kept alive, so its address cannot be
+        # handed to another tensor) and its version counter at build time
+        self.source = source if source is not None else samples
+        self.version = self.source._version
+        self.built = False
+
+    def matches(self, source):
+        return (source is self.source or (
+            source.data_ptr() == self.source.data_ptr() and source.shape == self.source.shape
+            and source.stride() == self.source.stride() and source.dtype == self.source.dtype
+            and source.device == self.source.device)) and source._version == self.version
+
+    def check(self):
+        if _error_flag(self.workspace, _lib.load().pigs_samples_error_offset()):
+            raise _lib.PigsError("samples build: the cell scan timed out waiting for a predecessor workgroup")
+
+
 class Plan:
-    """The binned structure built by ``preprocess`` (C ABI: pigs_plan_*): an opaque device
-    workspace plus the scalars every call on it must repeat.  Immutable once built; autograd
-    nodes keep a reference, so later ``preprocess`` calls never disturb a pending backward."""
+    """The Gaussian half of what ``preprocess`` builds (C ABI: pigs_plan_*): the Gaussians binned
+    into the multi-level grid and the per-tile lists, on top of a :class:`SamplePlan`.  Immutable
+    once built; autograd nodes keep a reference, so later ``preprocess`` calls never disturb a
+    pending backward."""
 
-    __slots__ = ("workspace", "N", "M", "c", "q_max")
+    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max")
 
-    def __init__(self, means, values, conics, samples, q_max):
+    def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
         key = (self.N, self.M, self.c)
@@ -89,12 +128,23 @@ class Plan:
             nbytes = _WORKSPACE_BYTES[key] = lib.pigs_plan_workspace_bytes(self.N, self.M, self.c)
         if nbytes == 0:
             raise _lib.PigsError(f"binned path does not support N={self.N} M={self.M} c={self.c}")
+        if sample_plan is None:
+            sample_plan = SamplePlan(samples, source)
+        self.samples = sample_plan
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
+        sws = sample_plan.workspace
         with _on_device(means.device):
-            rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, self.N, self.M, self.c, self.q_max,
+            rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, _ptr(sws), sws.numel(),
+                                     0 if sample_plan.built else 1, self.N, self.M, self.c, self.q_max,
                                      _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
                                      _stream(means.device))
         _lib.check(rc, "pigs_plan_build")
+        sample_plan.built = True
+
+    def check(self):
+        self.samples.check()
+        if _error_flag(self.workspace, _lib.load().pigs_plan_error_offset()):
+            raise _lib.PigsError("plan build: the cell scan timed out waiting for a predecessor workgroup")
 
     @staticmethod
     def supported(means, values, samples):
@@ -116,7 +166,9 @@ def forward_raw(means, values, conics, samples, mask, plan=None):
     if M > 0:
         with _on_device(means.device):
             if plan is not None:
-                rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
+                sws = plan.samples.workspace
+                rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), _ptr(sws), sws.numel(),
+                                           N, M, c, plan.q_max, mask,
                                            _ptr(outs[0]), _ptr(outs[1]), _ptr(_slot2(outs)), _ptr(outs[3]),
                                            _stream(means.device))
                 _lib.check(rc, "pigs_plan_forward")
@@ -141,7 +193,9 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
     if N > 0:
         with _on_device(means.device):
             if plan is not None and M > 0:
-                rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), N, M, c, plan.q_max, mask,
+                sws = plan.samples.workspace
+                rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), _ptr(sws), sws.numel(),
+                                            N, M, c, plan.q_max, mask,
                                             _ptr(gouts[0]), _ptr(gouts[1]), _ptr(_slot2(gouts)),
                                             _ptr(gouts[3]), _ptr(g_means), _ptr(g_conics), _ptr(g_values),
                                             _stream(means.device))
@@ -205,6 +259,12 @@ class GaussianSampler:
     40); ``"auto"`` picks
     binned for float32, d = 2, c <= 2 once N*M >= 2**26 pairs, where the plan pays for itself.
 
+    ``reuse_samples`` (extension, keyword only; binned path): when ``preprocess`` is called again with the
+    very same samples tensor (same storage, shape and version counter, i.e. not written to in
+    between) the sorted sample structure of the previous call is reused and only the Gaussian half
+    of the plan is rebuilt -- the reference's roll-out binds new Gaussians to a fixed grid every
+    step (main_pn.py:317-324).  ``False`` rebuilds everything every time.
+
     ``fuse`` (extension, keyword only) controls how many derivative orders one launch computes:
     ``"auto"`` -- the first ``sample_*`` call after a ``preprocess`` computes orders 0..2 in one
     launch when the problem is small enough to be launch-bound (M <= 65536), otherwise only the
@@ -215,7 +275,10 @@ class GaussianSampler:
     FUSE_AUTO_MAX_POINTS = 1 << 16
     BINNED_AUTO_MIN_PAIRS = 1 << 26     # dense: ~1.2e12 pairs/s; the plan costs ~32 us to build
 
-    def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None):
+    _warned_samples_grad = False
+
+    def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
+                 reuse_samples=True):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):
@@ -229,9 +292,12 @@ class GaussianSampler:
         self.q_max_order3 = float(q_max_order3) if q_max_order3 is not None else self.q_max + 8.0
         if self.q_max_order3 < self.q_max:
             raise ValueError("q_max_order3 must not be below q_max")
+        self.reuse_samples = bool(reuse_samples)
         self._plan3 = None
         self._inputs = None
         self._plan = None
+        self._sample_plan = None
+        self._samples_source = None
         self._cache = {}
         _lib.load()  # fail at construction, not at first use, if the HIP library is missing
 
@@ -280,8 +346,15 @@ class GaussianSampler:
             raise ValueError(f"samples must be [M, {d}], got {tuple(samples.shape)}")
         # no gradient flows to the sample points (the reference requests none from the sampler:
         # test_derivatives.py:123 asks for (means, values, conics) only)
+        if samples.requires_grad and torch.is_grad_enabled() and not GaussianSampler._warned_samples_grad:
+            GaussianSampler._warned_samples_grad = True
+            import warnings
+            warnings.warn("GaussianSampler: samples.requires_grad is set, but the sampler returns no gradient "
+                          "with respect to the sample points (as the reference, whose tests ask for the gradients "
+                          "of means, values and conics only); use the derivative outputs instead", stacklevel=2)
         self._inputs = (means.contiguous(), values.contiguous(), conics.contiguous(),
                         samples.detach().contiguous())
+        self._samples_source = samples
         self._cache = {}
         self._plan = None
         self._plan3 = None
@@ -290,12 +363,24 @@ class GaussianSampler:
         use_plan = self.backend == "binned" or (
             self.backend == "auto" and N * sc.shape[0] >= self.BINNED_AUTO_MIN_PAIRS)
         if use_plan and Plan.supported(mc, vc, sc):
-            with torch.no_grad():
-                self._plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, self.q_max)
-            if self.debug:
-                torch.cuda.synchronize(means.device)
+            self._plan = self._build_plan(self.q_max)
         elif self.backend == "binned" and N > 0 and sc.shape[0] > 0:
             raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 2")
+
+    def _build_plan(self, q_max):
+        """A plan for the bound inputs; the samples half is reused when ``preprocess`` was handed the
+        same unmodified samples tensor as last time (``reuse_samples``)."""
+        mc, vc, cc, sc = self._inputs
+        sp = self._sample_plan
+        if sp is not None and not (self.reuse_samples and sp.matches(self._samples_source)):
+            sp = None
+        with torch.no_grad():
+            plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source)
+        self._sample_plan = plan.samples
+        if self.debug:
+            torch.cuda.synchronize(mc.device)
+            plan.check()
+        return plan
 
     # ------------------------------------------------------------------ sampling
     def _require_inputs(self):
@@ -308,9 +393,7 @@ class GaussianSampler:
         if self._plan is None or not mask & 8 or self.q_max_order3 == self.q_max:
             return self._plan
         if self._plan3 is None:
-            mc, vc, cc, sc = self._inputs
-            with torch.no_grad():
-                self._plan3 = Plan(mc.detach(), vc.detach(), cc.detach(), sc, self.q_max_order3)
+            self._plan3 = self._build_plan(self.q_max_order3)
         return self._plan3
 
     def _compute(self, mask):
