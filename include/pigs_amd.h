@@ -138,6 +138,16 @@ int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samp
 size_t pigs_samples_error_offset(void);
 size_t pigs_plan_error_offset(void);
 
+/* Introspection for tools and tests (never needed to use a plan): where the tile lists sit inside a
+ * plan workspace.  info[0] = tiles, info[1] = entries per list slab, info[2] = byte offset of the
+ * tile headers (8 uint32 each: [0] = count | mode << 30; mode 0 = list of `count` entries `sorted
+ * Gaussian index | group mask << 28`, mode 1 = `count` record ranges {first, length}; [1..4] = the
+ * lengths of the four group lists), info[3] = byte offset of the tile-list slabs (uint32[tiles][slab]),
+ * info[4] = byte offset of the sorted -> caller Gaussian index table (uint32[N]), info[5] = byte
+ * offset of the group-list slabs (uint32[tiles][4][slab], sorted Gaussian indices).
+ * Returns PIGS_ERR_UNSUPPORTED for sizes the binned path does not take. */
+int pigs_plan_layout_info(int64_t N, int64_t M, int c, int64_t info[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ SIGNATURES = {
     "pigs_build_covariances_backward": (_i, [_i, _i64] + [_vp] * 6 + [_vp]),
     "pigs_samples_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "pigs_plan_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i]),
+    "pigs_plan_layout_info": (_i, [_i64, _i64, _i, ctypes.POINTER(_i64)]),
     "pigs_samples_error_offset": (ctypes.c_size_t, []),
     "pigs_plan_error_offset": (ctypes.c_size_t, []),
     "pigs_samples_build": (_i, [_vp, ctypes.c_size_t, _i64, _vp, _vp]),

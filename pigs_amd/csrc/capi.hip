@@ -89,6 +89,11 @@ size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c) { return plan_work
 size_t pigs_samples_error_offset(void) { return samples_error_offset(); }
 size_t pigs_plan_error_offset(void) { return plan_error_offset(); }
 
+int pigs_plan_layout_info(int64_t N, int64_t M, int c, int64_t info[6]) {
+    if (!info) return PIGS_ERR_INVALID;
+    return plan_layout_info(N, M, c, info);
+}
+
 int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream) {
     if (M < 0 || !samples) return PIGS_ERR_INVALID;
     return samples_build(samples_ws, samples_ws_bytes, M, samples, (hipStream_t)stream);

@@ -34,6 +34,7 @@ int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, i
 int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
                   float q_max, int mask, const void* const* gout, void* g_means, void* g_conics, void* g_values,
                   hipStream_t stream);
+int plan_layout_info(int64_t N, int64_t M, int c, int64_t* info);
 size_t samples_error_offset();
 size_t plan_error_offset();
 

@@ -25,11 +25,13 @@
 //      32-byte records: the cells within one cell of the rectangle, per level.
 //    * per TILE the list of Gaussians whose ellipse reaches the bounding box of the tile's points
 //      (exact ellipse / rectangle test), each entry carrying a 4-bit mask of the tile's GROUPS
-//      whose own box it reaches: entry = sorted index | mask << 28.  Forward, backward and every
-//      further sample_* call of the same preprocess read these lists; none of them traverses the
-//      grid again.  A list that would not fit its slab (very wide Gaussians) is replaced by the
-//      grid's record ranges around the tile (every Gaussian in them is evaluated for the whole
-//      tile), and by the single range [0, N) when even those do not fit.
+//      whose own box it reaches: entry = sorted index | mask << 28 (read by the backward); and per
+//      GROUP the same Gaussians split by that mask into four packed index lists (read by the
+//      forward: every DPP row streams its own list, no compaction at sampling time).  Forward,
+//      backward and every further sample_* call of the same preprocess read these lists; none of
+//      them traverses the grid again.  A list that would not fit its slab (very wide Gaussians) is
+//      replaced by the grid's record ranges around the tile (every Gaussian in them is evaluated
+//      for the whole tile), and by the single range [0, N) when even those do not fit.
 //
 // Cut-off: a (point, Gaussian) pair is evaluated iff the Gaussian's ellipse q <= q_max reaches
 // the bounding box of the point's 16-point group.  Dropped terms are < exp(-q_max/2) of the
@@ -59,7 +61,9 @@ constexpr int PLAN_BBOX_BLOCKS = 256;
 // tile list entries: sorted Gaussian index | group mask << LIST_IDX_BITS
 constexpr int LIST_IDX_BITS = 28;
 constexpr uint32_t LIST_IDX_MASK = (1u << LIST_IDX_BITS) - 1u;
-// tile header: count | mode << 30
+// tile header, 8 words: [0] = count | mode << 30 (entries of the tile list, or record ranges), [1..4] =
+// lengths of the four group lists (list mode)
+constexpr int TILE_HDR_WORDS = 8;
 constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u;
 constexpr int TILE_MODE_SHIFT = 30;
 constexpr uint32_t TILE_COUNT_MASK = (1u << TILE_MODE_SHIFT) - 1u;
@@ -136,9 +140,9 @@ struct PlanLayout {
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     uint32_t scan_blocks;      // workgroups of the scan = ceil((gcells + 1) / PLAN_SCAN_BLOCK)
     uint32_t ntiles;           // ceil(M / 64)
-    uint32_t list_cap;         // entries per tile slab, multiple of 64
+    uint32_t list_cap;         // entries per list slab (one tile list + four group lists per tile), multiple of 16
     size_t off_params, off_counts, off_agg, off_starts, off_gkey, off_rec, off_box, off_g2o, off_gacc, off_hdr,
-        off_lists, total_bytes;
+        off_tlist, off_glist, total_bytes;
 };
 
 // Counter spacing of a level with `cells` cells: device-scope atomics on one 128-byte line
@@ -151,13 +155,13 @@ __host__ __device__ inline int level_shift(uint32_t cells) {     // cells: a pow
     return sh < 0 ? 0 : sh > 5 ? 5 : sh;
 }
 
-// Slab of a tile's list: room for every Gaussian when N is small (such a list can never
-// overflow), 1 024 entries (64 bytes per sample point) beyond; what does not fit is kept as
-// record ranges (plan.h header).
+// Slab of a list: room for every Gaussian when N is small (such a list can never overflow), 512
+// entries beyond (5 slabs per tile: 160 bytes per sample point); what does not fit is kept as
+// record ranges (header of this file).
 inline uint32_t list_cap_for(int64_t N) {
-    int64_t cap = (N + 63) / 64 * 64;
-    if (cap < 64) cap = 64;
-    if (cap > 1024) cap = 1024;
+    int64_t cap = (N + 15) / 16 * 16;
+    if (cap < 16) cap = 16;
+    if (cap > 512) cap = 512;
     return (uint32_t)cap;
 }
 
@@ -187,12 +191,13 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_agg = o;      o = align_up(o + sizeof(uint64_t) * (size_t)p.scan_blocks, 256);
     p.off_starts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
     p.off_gkey = o;     o = align_up(o + sizeof(uint2) * (size_t)N, 256);      // {cell key, rank in cell}
-    p.off_rec = o;      o = align_up(o + 32 * (size_t)N, 256);
+    p.off_rec = o;      o = align_up(o + 32 * ((size_t)N + 1), 256);           // + the all-zero record N
     p.off_box = o;      o = align_up(o + 16 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
     p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [8][N]
-    p.off_hdr = o;      o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles, 256);
-    p.off_lists = o;    o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles * p.list_cap, 256);
+    p.off_hdr = o;      o = align_up(o + sizeof(uint32_t) * TILE_HDR_WORDS * (size_t)p.ntiles, 256);
+    p.off_tlist = o;    o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles * p.list_cap, 256);
+    p.off_glist = o;    o = align_up(o + sizeof(uint32_t) * 4 * (size_t)p.ntiles * p.list_cap, 256);
     p.total_bytes = o;
     return p;
 }
@@ -208,11 +213,12 @@ struct SamplesView {
 struct PlanView {
     const PlanParams* params;
     const uint32_t* starts;       // [gcells + 1] exclusive scan of the Gaussian cell counters
-    const float4* rec;            // [2N] sorted records: {mux, muy, a, b}, {b, c, v0, v1}  (c <= 2)
+    const float4* rec;            // [2N + 2] sorted records: {mux, muy, a, b}, {c, v0, v1, 0}  (c <= 2); record N is all zero
     const float4* gbox;           // [N] sorted: {mux, muy, hx, hy} = centre and half extents of the q <= q_max ellipse
     const uint32_t* g2o;          // sorted Gaussian -> original index
-    const uint32_t* hdr;          // [ntiles] count | mode << 30
-    const uint32_t* lists;        // [ntiles][list_cap]
+    const uint32_t* hdr;          // [ntiles][TILE_HDR_WORDS]
+    const uint32_t* tlist;        // [ntiles][list_cap]     tile lists (entries with group masks) / record ranges
+    const uint32_t* glist;        // [ntiles][4][list_cap]  group lists (sorted Gaussian indices)
     uint32_t N, list_cap;
     int G0, L;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];

@@ -369,9 +369,13 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         const uint32_t pos = a.starts[kr.x] + kr.y;
         float v[2] = {0.f, 0.f};
         for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
-        // {mux, muy, a, b}, {b, c, v0, v1}
+        // {mux, muy, a, b}, {c, v0, v1, 0}
         a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
-        a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 1], a.conics[3 * i + 2], v[0], v[1]);
+        a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 2], v[0], v[1], 0.f);
+        if (i == 0) {         // record N: all zero (v = 0 contributes nothing), what list positions behind a list's end read
+            a.rec[2 * (size_t)a.N] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a.rec[2 * (size_t)a.N + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         {   // bounding box of the q <= q_max ellipse: half extents sqrt(q_max Sigma_xx), sqrt(q_max Sigma_yy)
             const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
             const float k = a.q_max / (ca * cc - cb * cb);
@@ -548,10 +552,10 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
                 const float4 A0 = pv.rec[2 * i0], B0 = pv.rec[2 * i0 + 1];
                 float4 A1 = A0, B1 = B0;
                 if (b0 + 64 < cn) { A1 = pv.rec[2 * i1]; B1 = pv.rec[2 * i1 + 1]; }
-                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.y, bx0, by0, bx1, by1, pv.q_max));
+                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.x, bx0, by0, bx1, by1, pv.q_max));
                 if (m0) batch(A0, B0, m0, i0);
                 if (b0 + 64 < cn) {
-                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.y, bx0, by0, bx1, by1, pv.q_max));
+                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.x, bx0, by0, bx1, by1, pv.q_max));
                     if (m1) batch(A1, B1, m1, i1);
                 }
             }
@@ -605,7 +609,8 @@ struct ListArgs {
     PlanView pv;
     SamplesView sv;
     uint32_t* hdr;
-    uint32_t* lists;
+    uint32_t* tlist;
+    uint32_t* glist;
 };
 
 __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
@@ -635,8 +640,11 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     wave_box_from_rows_dpp(x0, x1, y0, y1);
     const float bx0 = x0, bx1 = x1, by0 = y0, by1 = y1;
 
-    uint32_t* slab = a.lists + (size_t)tile * pv.list_cap;
-    uint32_t n = 0;
+    const uint32_t cap = pv.list_cap;
+    uint32_t* tl = a.tlist + (size_t)tile * cap;
+    uint32_t* gl = a.glist + (size_t)tile * 4 * cap;
+    uint32_t* hd = a.hdr + (size_t)tile * TILE_HDR_WORDS;
+    uint32_t n = 0, ng[4] = {0, 0, 0, 0};
     bool overflow = false;
     traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds, true,
              [](int, uint32_t, uint32_t) {},
@@ -645,20 +653,36 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // a group without a point (the ragged last tile) has an inverted box: never needed
-            if (gx0[g] <= gx1[g] && ellipse_reaches_rect(A, B.y, gx0[g], gy0[g], gx1[g], gy1[g], pv.q_max)) gm |= 1u << g;
+            if (gx0[g] <= gx1[g] && ellipse_reaches_rect(A, B.x, gx0[g], gy0[g], gx1[g], gy1[g], pv.q_max)) gm |= 1u << g;
         }
-        const bool keep = (mask >> lane & 1ull) && gm != 0u;
-        const uint64_t km = __ballot(keep);
+        if (!(mask >> lane & 1ull)) gm = 0u;
+        const uint64_t km = __ballot(gm != 0u);
         const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
-        if (n + cnt <= pv.list_cap) {
-            if (keep) slab[n + (uint32_t)lanes_below(km)] = j | (gm << LIST_IDX_BITS);
+        if (n + cnt <= cap) {
+            if (gm != 0u) tl[n + (uint32_t)lanes_below(km)] = j | (gm << LIST_IDX_BITS);
         } else {
             overflow = true;
         }
         n += cnt;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint64_t mg = __ballot(gm >> g & 1u);
+            const uint32_t cg = (uint32_t)__builtin_popcountll(mg);
+            if (ng[g] + cg <= cap) {
+                if (gm >> g & 1u) gl[g * cap + ng[g] + (uint32_t)lanes_below(mg)] = j;
+            }
+            ng[g] += cg;        // a group list is never longer than the tile list: overflow is caught above
+        }
     });
     if (!overflow) {
-        if (lane == 0) a.hdr[tile] = n | (TILE_MODE_LIST << TILE_MODE_SHIFT);
+        if (lane < TILE_HDR_WORDS) {
+            uint32_t w = 0;
+            if (lane == 0) w = n | (TILE_MODE_LIST << TILE_MODE_SHIFT);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (lane == 1 + g) w = ng[g];
+            hd[lane] = w;
+        }
         return;
     }
     // The list does not fit: keep the grid's record ranges around the tile instead (pairs {first,
@@ -670,10 +694,10 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         const bool keep = lane < nrow && len > 0;
         const uint64_t km = __ballot(keep);
         const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
-        if (2 * (nr + cnt) <= pv.list_cap) {
+        if (2 * (nr + cnt) <= cap) {
             if (keep) {
                 const uint32_t p = 2 * (nr + (uint32_t)lanes_below(km));
-                slab[p] = jb; slab[p + 1] = len;
+                tl[p] = jb; tl[p + 1] = len;
             }
         } else {
             fits = false;
@@ -682,19 +706,226 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     },
              [](const float4, const float4, uint64_t, uint32_t) {});
     if (!fits) {
-        if (lane == 0) { slab[0] = 0; slab[1] = pv.N; }
+        if (lane == 0) { tl[0] = 0; tl[1] = pv.N; }
         nr = 1;
     }
-    if (lane == 0) a.hdr[tile] = nr | (TILE_MODE_RANGES << TILE_MODE_SHIFT);
+    if (lane < TILE_HDR_WORDS) hd[lane] = lane == 0 ? (nr | (TILE_MODE_RANGES << TILE_MODE_SHIFT)) : 0u;
 }
 
 // ------------------------------------------------------------------------------------------
-// Sampling kernels.  One wave = one tile; a step = 64 list entries (lane = entry): their records
-// go to the wave's LDS (slot = lane), their group masks are split into four per-row index lists
-// holding LDS byte offsets, padded with the offset of an all-zero record to the longest of the
-// four; then the rows are evaluated together, every row on its own list.
+// Sampling kernels.  One wave = one tile; a step = 64 list entries (lane = entry).
 // ------------------------------------------------------------------------------------------
-constexpr int LIST_PAD = 2 * PIGS_FWD_UNROLL > 8 ? 2 * PIGS_FWD_UNROLL : 8;
+struct Rec {
+    float mu[2], con[3], v[2];
+};
+__device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
+    Rec r;
+    r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.x;
+    r.v[0] = B.y; r.v[1] = B.z;
+    return r;
+}
+
+// Walks a tile's list (or its ranges): `step(idx, gm, have)` for every 64 entries.
+template <typename Step>
+__device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step) {
+    const uint32_t hdr = pv.hdr[(size_t)tile * TILE_HDR_WORDS];
+    const uint32_t count = hdr & TILE_COUNT_MASK;
+    const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
+    if ((hdr >> TILE_MODE_SHIFT) == TILE_MODE_LIST) {
+        for (uint32_t e0 = 0; e0 < count; e0 += 64) {
+            const bool have = e0 + (uint32_t)lane < count;
+            const uint32_t e = have ? slab[e0 + lane] : 0u;
+            step(e & LIST_IDX_MASK, e >> LIST_IDX_BITS, have);
+        }
+    } else {
+        for (uint32_t r = 0; r < count; ++r) {
+            const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
+            for (uint32_t o = 0; o < len; o += 64) {
+                const bool have = o + (uint32_t)lane < len;
+                step(have ? j0 + o + (uint32_t)lane : j0, have ? 0xFu : 0u, have);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward.  Every group (DPP row) of the wave keeps its own queue of RECORDS in LDS: a step's
+// entries are appended to the queues of the groups in their masks (ballot + mbcnt give the
+// positions; a record is copied up to four times), each queue taking what it has room for; when
+// a queue is full -- or the list ends -- the queues are evaluated row-wise: in one instruction
+// every row works on its OWN Gaussian, read from LDS at an address that is affine in the loop
+// counter (no index indirection: the reads of the next rows are in flight while the current ones
+// are evaluated).  Queues shorter than the longest are padded with all-zero records (v = 0:
+// contributes nothing); on long lists every queue is full at every flush but the last.
+// A record in LDS is {mux, muy, a, b}, {c, v0, v1, -}: one ds_read_b128 + one ds_read_b64 (c = 1).
+// The reads are inline asm: hipcc fuses 8-byte LDS reads of neighbouring rows into ds_read2_b64,
+// which moves 16 bytes in 8 LDS cycles where ds_read_b128 takes 4 (MI355X_MICROARCH.md, LDS
+// table), and collapses a source-level prefetch into load-then-wait.
+// ------------------------------------------------------------------------------------------
+#ifndef PIGS_GROUP_CAP
+#define PIGS_GROUP_CAP 32        // records per group queue
+#endif
+constexpr int GROUP_CAP = PIGS_GROUP_CAP;
+static_assert(GROUP_CAP >= 8 && GROUP_CAP % PIGS_FWD_UNROLL == 0, "queue capacity");
+
+struct FwdLds {
+    static constexpr int GSTRIDE = GROUP_CAP * 32 + 32;            // bytes; + 32: the four queues start on different banks
+    float4 rec[(4 * GSTRIDE + PIGS_FWD_UNROLL * 32) / 16];        // tail: the prefetch behind the last row
+};
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// LDS byte address of a __shared__ object (for ds_* inline asm)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int C> struct LdsRec;
+template <> struct LdsRec<1> { f4v a; f2v b; };
+template <> struct LdsRec<2> { f4v a; f4v b; };
+// issue the reads of the record at addr + OFF (no wait: lds_rec_wait before the first use)
+template <int OFF>
+__device__ __forceinline__ void lds_rec_issue(LdsRec<1>& r, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
+                 : "=v"(r.a), "=v"(r.b) : "v"(addr), "i"(OFF), "i"(OFF + 16));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_rec_issue(LdsRec<2>& r, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=v"(r.a), "=v"(r.b) : "v"(addr), "i"(OFF), "i"(OFF + 16));
+}
+template <int C>
+__device__ __forceinline__ void lds_rec_wait(LdsRec<C>* r) {      // r[0], r[1]: every pending destination
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0].a), "+v"(r[0].b), "+v"(r[1].a), "+v"(r[1].b));
+}
+template <int C>
+__device__ __forceinline__ Rec rec_of(const LdsRec<C>& x) {
+    Rec r;
+    r.mu[0] = x.a.x; r.mu[1] = x.a.y; r.con[0] = x.a.z; r.con[1] = x.a.w; r.con[2] = x.b.x; r.v[0] = x.b.y;
+    if constexpr (C == 2) r.v[1] = x.b.z;
+    else r.v[1] = 0.f;
+    return r;
+}
+
+// rows: a multiple of 2.  Two register sets take turns: while one pair of rows is evaluated the
+// reads of the next pair are in flight (the last issue reads the two rows behind the queue: inside
+// the LDS block, never used).
+template <int C, int MASK>
+__device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const FwdLds& lds, int rows, int lane) {
+    static_assert(PIGS_FWD_UNROLL == 2, "two rows per register set");
+    uint32_t q = lds_addr(lds.rec) + (uint32_t)(lane >> 4) * FwdLds::GSTRIDE;
+    LdsRec<C> ra[2], rb[2];
+    auto eval2 = [&](const LdsRec<C>* r) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const Rec x = rec_of<C>(r[u]);
+            fwd_accumulate<float, 2, C, MASK>(acc, s, x.mu, x.con, x.v);
+        }
+    };
+    lds_rec_issue<0>(ra[0], q);
+    lds_rec_issue<32>(ra[1], q);
+    int k = 0;
+    for (; k + 4 <= rows; k += 4) {
+        lds_rec_wait<C>(ra);
+        lds_rec_issue<64>(rb[0], q);
+        lds_rec_issue<96>(rb[1], q);
+        eval2(ra);
+        lds_rec_wait<C>(rb);
+        lds_rec_issue<128>(ra[0], q);
+        lds_rec_issue<160>(ra[1], q);
+        q += 128;
+        eval2(rb);
+    }
+    lds_rec_wait<C>(ra);
+    if (k < rows) eval2(ra);
+}
+
+// register budget: 8 waves/SIMD (64 VGPRs) for the narrow variants, fewer waves for the wide ones
+// (c = 2 with orders up to 3: 12-20 accumulators) so that they do not spill
+template <int C, int MASK>
+constexpr int fwd_waves() {
+    constexpr int n = FwdLayout<2, C, MASK>::N;
+    return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1)) ? PIGS_FWD_WAVES : 6;
+}
+template <int C, int MASK>
+__global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kernel(
+    PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
+    float* __restrict__ o3) {
+    using L = FwdLayout<2, C, MASK>;
+    constexpr int U = PIGS_FWD_UNROLL;
+    __shared__ FwdLds lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
+    if (tile >= sv.ntiles) return;
+    FwdLds& lds = lds_all[wave];
+    char* const qbase = (char*)lds.rec;
+    const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
+    const bool valid = m < sv.M;
+    const SPoint sp = sv.spts[valid ? m : sv.M - 1];      // lanes behind the last point repeat it (never stored)
+    const float s[2] = {sp.x, sp.y};
+    float acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
+    const int g = lane >> 4, i = lane & 15;
+    const uint32_t* hd = pv.hdr + (size_t)tile * TILE_HDR_WORDS;
+    const uint32_t h0 = hd[0];
+    // one chunk: every row fills its queue with `rows` records (its own list's, or the all-zero record
+    // behind the list's end), two rounds of 16 in flight together, and the rows are evaluated
+    auto chunk = [&](int rows, auto&& index_of) {
+        static_assert(GROUP_CAP == 32, "two rounds of 16 records per chunk");
+        rows = __builtin_amdgcn_readfirstlane((rows + U - 1) / U * U);
+        const uint32_t j0 = index_of(i), j1 = index_of(16 + i);
+        const float4 A0 = pv.rec[2 * (size_t)j0], B0 = pv.rec[2 * (size_t)j0 + 1];
+        float4 A1 = A0, B1 = B0;
+        if (rows > 16) { A1 = pv.rec[2 * (size_t)j1]; B1 = pv.rec[2 * (size_t)j1 + 1]; }
+        float4* dst = (float4*)(qbase + g * FwdLds::GSTRIDE + i * 32);
+        wave_lds_fence();
+        dst[0] = A0;
+        *(float2*)(dst + 1) = make_float2(B0.x, B0.y);
+        if constexpr (C == 2) *(float2*)((char*)(dst + 1) + 8) = make_float2(B0.z, 0.f);
+        if (rows > 16) {
+            dst[32] = A1;
+            *(float2*)(dst + 33) = make_float2(B1.x, B1.y);
+            if constexpr (C == 2) *(float2*)((char*)(dst + 33) + 8) = make_float2(B1.z, 0.f);
+        }
+        wave_lds_fence();
+#ifndef PIGS_DEBUG_SKIP_EVAL
+        evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
+#else
+        acc[0] += (float)rows + ((const float*)lds.rec)[lane];
+#endif
+    };
+    if ((h0 >> TILE_MODE_SHIFT) == TILE_MODE_LIST) {
+        const uint32_t ng = hd[1 + g];                                    // this row's list length
+        const uint32_t* gl = pv.glist + ((size_t)tile * 4 + g) * pv.list_cap;
+        uint32_t nmax = hd[1] > hd[2] ? hd[1] : hd[2];
+        nmax = hd[3] > nmax ? hd[3] : nmax;
+        nmax = hd[4] > nmax ? hd[4] : nmax;
+        for (uint32_t base = 0; base < nmax; base += GROUP_CAP) {
+            const int rows = (int)(nmax - base < GROUP_CAP ? nmax - base : GROUP_CAP);
+            chunk(rows, [&](int p) { return base + p < ng ? gl[base + p] : pv.N; });
+        }
+    } else {
+        const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
+        const uint32_t count = h0 & TILE_COUNT_MASK;
+        for (uint32_t r = 0; r < count; ++r) {
+            const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
+            for (uint32_t base = 0; base < len; base += GROUP_CAP) {
+                const int rows = (int)(len - base < GROUP_CAP ? len - base : GROUP_CAP);
+                chunk(rows, [&](int p) { return base + p < len ? j0 + base + p : pv.N; });
+            }
+        }
+    }
+    if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward helpers: a step's records go to the wave's LDS once (slot = lane); the group masks are
+// split into four per-row index lists holding LDS byte offsets, padded with the offset of an
+// all-zero record to the longest of the four.
+// ------------------------------------------------------------------------------------------
+constexpr int LIST_PAD = 8;
 struct TileLds {
     float4 rec[TILE_POINTS + 1][2];            // slot 64: the all-zero record (v = 0: contributes nothing)
     uint32_t list[4][TILE_POINTS + LIST_PAD];  // byte offsets into rec
@@ -720,110 +951,8 @@ __device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane) {
     return rows;
 }
 
-struct Rec {
-    float mu[2], con[3], v[2];
-};
-__device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
-    Rec r;
-    r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.y;
-    r.v[0] = B.z; r.v[1] = B.w;
-    return r;
-}
-
-template <int C, int MASK>
-__device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const TileLds& lds, int rows, int lane) {
-    constexpr int U = PIGS_FWD_UNROLL;       // rows per iteration (independent chains for ILP)
-    if (rows == 0) return;
-    const char* base = (const char*)&lds.rec[0][0];
-    const uint32_t* lst = lds.list[lane >> 4];
-    float4 a[U], b[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t off = lst[u];
-        a[u] = *(const float4*)(base + off);
-        b[u] = *(const float4*)(base + off + 16);
-    }
-    for (int k = 0; k < rows; k += U) {
-        float4 na[U], nb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t off = lst[k + U + u];
-            na[u] = *(const float4*)(base + off);
-            nb[u] = *(const float4*)(base + off + 16);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const Rec r = make_rec(a[u], b[u]);
-            fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { a[u] = na[u]; b[u] = nb[u]; }
-    }
-}
-
-// Walks a tile's list (or its ranges): `step(idx, gm, have)` for every 64 entries.
-template <typename Step>
-__device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step) {
-    const uint32_t hdr = pv.hdr[tile];
-    const uint32_t count = hdr & TILE_COUNT_MASK;
-    const uint32_t* slab = pv.lists + (size_t)tile * pv.list_cap;
-    if ((hdr >> TILE_MODE_SHIFT) == TILE_MODE_LIST) {
-        for (uint32_t e0 = 0; e0 < count; e0 += 64) {
-            const bool have = e0 + (uint32_t)lane < count;
-            const uint32_t e = have ? slab[e0 + lane] : 0u;
-            step(e & LIST_IDX_MASK, e >> LIST_IDX_BITS, have);
-        }
-    } else {
-        for (uint32_t r = 0; r < count; ++r) {
-            const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
-            for (uint32_t o = 0; o < len; o += 64) {
-                const bool have = o + (uint32_t)lane < len;
-                step(have ? j0 + o + (uint32_t)lane : j0, have ? 0xFu : 0u, have);
-            }
-        }
-    }
-}
-
-// register budget: 8 waves/SIMD (64 VGPRs) for the narrow variants, fewer waves for the wide ones
-// (c = 2 with orders up to 3: 12-20 accumulators) so that they do not spill
-template <int C, int MASK>
-constexpr int fwd_waves() {
-    constexpr int n = FwdLayout<2, C, MASK>::N;
-    return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1)) ? PIGS_FWD_WAVES : 6;
-}
-template <int C, int MASK>
-__global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kernel(
-    PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
-    float* __restrict__ o3) {
-    using L = FwdLayout<2, C, MASK>;
-    __shared__ TileLds lds_all[4];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
-    if (tile >= sv.ntiles) return;
-    TileLds& lds = lds_all[wave];
-    const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
-    const bool valid = m < sv.M;
-    const SPoint sp = sv.spts[valid ? m : sv.M - 1];      // lanes behind the last point repeat it (never stored)
-    const float s[2] = {sp.x, sp.y};
-    if (lane < 2) lds.rec[TILE_POINTS][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float acc[L::N];
-#pragma unroll
-    for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
-    for_each_step(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool) {
-        const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
-        wave_lds_fence();                      // the previous step's reads are behind us
-        lds.rec[lane][0] = A;
-        lds.rec[lane][1] = B;
-        const int rows = split_step<PIGS_FWD_UNROLL>(lds, gm, lane);
-        wave_lds_fence();
-        evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
-    });
-    if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
-}
-
 // ------------------------------------------------------------------------------------------
-// Backward: the same tile / list / LDS structure.  Every (row, Gaussian) pair of a step yields
+// Backward: the same tile / list structure.  Every (row, Gaussian) pair of a step yields
 // NV = 5 + c per-lane contributions that must be summed over the row's 16 points; the sums of the
 // (up to four) rows that work on the same Gaussian meet in an LDS table indexed by the entry's
 // slot (ds_add_f32), which is flushed once per step with one atomic per entry and value into
@@ -980,7 +1109,8 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     v.gbox = (const float4*)(b + p.off_box);
     v.g2o = (const uint32_t*)(b + p.off_g2o);
     v.hdr = (const uint32_t*)(b + p.off_hdr);
-    v.lists = (const uint32_t*)(b + p.off_lists);
+    v.tlist = (const uint32_t*)(b + p.off_tlist);
+    v.glist = (const uint32_t*)(b + p.off_glist);
     v.N = (uint32_t)p.N;
     v.list_cap = p.list_cap;
     v.G0 = p.G0; v.L = p.L;
@@ -992,6 +1122,14 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
 
 size_t samples_error_offset() { return offsetof(SampleParams, scan_error); }
 size_t plan_error_offset() { return offsetof(PlanParams, scan_error); }
+
+int plan_layout_info(int64_t N, int64_t M, int c, int64_t* info) {
+    if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
+    const PlanLayout p = make_plan_layout(N, M, c);
+    info[0] = p.ntiles; info[1] = p.list_cap; info[2] = (int64_t)p.off_hdr; info[3] = (int64_t)p.off_tlist;
+    info[4] = (int64_t)p.off_g2o; info[5] = (int64_t)p.off_glist;
+    return PIGS_OK;
+}
 
 size_t samples_workspace_bytes(int64_t M) {
     if (!samples_supported(M)) return 0;
@@ -1073,7 +1211,8 @@ static int run_build(bool do_samples, bool do_plan, void* sws, size_t sws_bytes,
         la.pv = make_view(p, ws, q_max);
         la.sv = make_samples_view(s, sws);
         la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
-        la.lists = (uint32_t*)((char*)ws + p.off_lists);
+        la.tlist = (uint32_t*)((char*)ws + p.off_tlist);
+        la.glist = (uint32_t*)((char*)ws + p.off_glist);
         hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 3) / 4), dim3(256), 0, stream, la);
     }
     return launch_status();
