@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the sampler hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2] [--kappa 0.5]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c4] [--kappa 0.5]
 
 One step = one pass of the hot path over one batch of synthetic input, through the reference's
 operator surface: ``GaussianSampler.preprocess(...)`` + one fused launch producing u, grad u and
 the Hessian (orders 0..2) for every sample point.  Inputs are resident in HBM before the timed
-region.  N > 1: launched by torch.distributed.run, one rank per GPU; the sample grid is sharded
-by rows (weak scaling: every rank owns a res x res block of a res x (N res) grid over the same
-65k Gaussians); the forward needs no collective, the backward all-reduces the parameter
-gradients (reported in the extra ``fwd_bwd`` field, not part of the timed K steps).
+region.  ``value`` times the COLD step: nothing is reused between steps (samples re-sorted, Gaussians
+re-binned, tile lists rebuilt every time); ``value_warm_plan`` is the same step when ``preprocess``
+is handed the same, unmodified samples tensor as before and reuses its sorted sample structure --
+the reference's roll-out pattern (main_pn.py:317-324).
+
+N > 1: launched by torch.distributed.run, one rank per GPU.  Default (``c3``) is weak scaling: every
+rank owns ~1 M points of a square grid of side round(1024 sqrt(N)) over the same 65k Gaussians.
+``--workload c4`` is BASELINE configs[3]: the 4096^2 grid sharded by rows over the ranks (strong
+scaling; one rank = all 16.8 M points).  The forward needs no collective; the backward all-reduces
+the parameter gradients as ONE packed [N,6] buffer (RCCL over xGMI): for N > 1 the line also carries
+``fwd_bwd.value`` = points/s of the whole preprocess + forward + backward + all-reduce step.
 
 Prints ONE JSON line on rank 0 (contract in the task description): metric, value (whole-job
-sample-points/s), roofline of the dominant kernel (HBM-bound designation of BASELINE.json),
-cpu_baseline (the reference's dense PyTorch algorithm on the host cores, bounded sample).
+sample-points/s), roofline of the dominant kernel (HBM-bound designation of BASELINE.json) with the
+VALU-issue figure beside it, roofline_bwd, cpu_baseline (the reference's dense PyTorch algorithm on
+the host cores, bounded sample).
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -29,6 +38,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 VALU_PAIR_PEAK = 3.6e12    # pairs/s: 157.3 TFLOP/s fp32 / 2 / ~22 issue slots per pair
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2       # wave-instructions/s: 1 024 SIMDs, one wave64 VALU op per 2 cycles
+ROW_VALU_INSTR = 21.25     # VALU instructions per evaluated row (16 points x 1 Gaussian x 4 rows of a wave), ISA count
+ROW_NS_UBENCH = 30.8       # ns per wave-row per SIMD of the bare row loop at 8 waves/SIMD (tools/ubench/rowloop.hip)
+PREHEAT_S = 0.25
 
 
 def parse():
@@ -36,10 +49,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4"])
     ap.add_argument("--kappa", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip kappa_1_3, two_streams, hipgraph_replay")
     ap.add_argument("--backend", default="auto", choices=["auto", "dense", "binned"])
     # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo, ranks share devices)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
@@ -48,15 +62,40 @@ def parse():
 
 def measured_traffic(workload, kappa, binned):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same command, corrected as MI355X_MICROARCH.md 'HBM' prescribes); None when no profile of
-    this exact configuration is committed."""
+    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, corrected
+    as MI355X_MICROARCH.md 'HBM' prescribes).  The record names the source hash of the library it was
+    measured on: (None, reason) when no profile of this exact configuration AND this exact source
+    is committed -- a stale figure is never reported."""
     try:
+        import importlib
+        B = importlib.import_module("pigs_amd.build")      # the module (the package re-exports its build())
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         key = f"{workload}:kappa={kappa}:{'binned' if binned else 'dense'}"
-        return table.get(key, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
+        rec = table.get(key)
+        if not rec:
+            return None, f"no PMC profile committed for {key}"
+        if rec.get("source_hash") != B.source_hash():
+            return None, f"profiles/pmc_traffic.json[{key}] was measured on other kernel sources (hash mismatch)"
+        return rec.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json[{key}] @ source {rec['source_hash'][:12]}"
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"{type(e).__name__}: {e}"
+
+
+def plan_rows(plan):
+    """Evaluated rows (16 points x 1 Gaussian, four per wave instruction) of one forward launch on this
+    plan, read from its tile headers: sum over the tiles of the longest group list, padded to 2."""
+    from pigs_amd import _lib
+    lib = _lib.load()
+    info = (ctypes.c_int64 * 6)()
+    if lib.pigs_plan_layout_info(plan.N, plan.M, plan.c, info) != 0:
         return None
+    ntiles, off_hdr = info[0], info[2]
+    hdr = plan.workspace[off_hdr:off_hdr + 32 * ntiles].view(torch.int32).reshape(ntiles, 8)
+    if int((hdr[:, 0] >> 30).ne(0).sum()) != 0:
+        return None                       # range-mode tiles: the headers do not hold the row count
+    ng = hdr[:, 1:5].to(torch.int64)
+    wave_rows = int(((ng.max(dim=1).values + 1) // 2 * 2).sum())
+    return {"wave_rows": wave_rows, "pairs": int(ng.sum()) * 16}
 
 
 def graph_replay(GaussianSampler, t, pts_d, backend, n):
@@ -176,158 +215,191 @@ def main():
     from pigs_amd import synthetic, sampler as S
 
     # ---------------- workload (seeded, generated on the CPU, then moved) ----------------
-    if a.workload == "c3":
-        nx = ny = 256
-        res = 1024
-    else:
-        nx, ny, res = 128, 64, 256
-    gs = synthetic.lattice_gaussians(nx, ny, a.kappa, seed=0)
-    # weak scaling (the grid shards by blocks of rows, the Gaussians are replicated): the
-    # global grid is the square side x side grid over [-1,1]^2 with ~res*res points per GPU
-    # (side = round(res * sqrt(world)): 1024, 1448, 2048, 2896 for 1, 2, 4, 8 GPUs -- isotropic
-    # spacing at every N); rank r owns rows [r*rows, (r+1)*rows), rows = side // world
-    side = int(round(res * math.sqrt(world)))
-    rows = side // world
-    pts = synthetic.grid_samples(side, side, row0=rank * rows, rows=rows)
+    def workload(kappa):
+        if a.workload == "c2":
+            nx, ny, res = 128, 64, 256
+        else:
+            nx = ny = 256
+            res = 1024
+        gs_ = synthetic.lattice_gaussians(nx, ny, kappa, seed=0)
+        if a.workload == "c4":
+            # BASELINE configs[3]: the 4096^2 grid sharded by rows over the ranks (strong scaling)
+            side_ = 4096
+            from pigs_amd.distributed import shard_bounds
+            r0, r1 = shard_bounds(side_, world, rank)
+        else:
+            # weak scaling (the grid shards by blocks of rows, the Gaussians are replicated):
+            # the global grid is the square side x side grid over [-1,1]^2 with ~res*res points per GPU
+            # (side = round(res * sqrt(world)): 1024, 1448, 2048, 2896 for 1, 2, 4, 8 GPUs -- isotropic
+            # spacing at every N); rank r owns rows [r*rows, (r+1)*rows), rows = side // world
+            side_ = int(round(res * math.sqrt(world)))
+            r0, r1 = rank * (side_ // world), (rank + 1) * (side_ // world)
+        pts_ = synthetic.grid_samples(side_, side_, row0=r0, rows=r1 - r0)
+        return gs_, pts_, side_, r1 - r0
+
+    gs, pts, side, rows = workload(a.kappa)
     N, M = gs["means"].shape[0], pts.shape[0]
     t = {k: v.float().to(dev) for k, v in gs.items()}
     pts_d = pts.float().to(dev)
-    sampler = GaussianSampler(False, fuse="all", backend=a.backend)
-
-    def step():
-        sampler.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
-        return sampler.sample((0, 1, 2))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.no_grad():
-        for _ in range(a.warmup):
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tmax = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    def timed_steps(step, warmup, steps):
+        """W untimed + exactly K timed steps between barrier + synchronize pairs; max over the ranks."""
+        for _ in range(warmup):
             step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            out = step()
+        for _ in range(steps):
+            step()
         barrier()
-        dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ms_per_step = dt / a.steps * 1e3
-    value = M * world / (dt / a.steps)
+        return max_over_ranks(time.perf_counter() - t0)
 
-    # ---------------- the same steps dealt round-robin to two HIP streams ----------------
-    # (extra figure, not `value`: independent evaluation steps -- frames of a roll-out -- can overlap;
-    # the latency-bound plan build of step k+1 then hides under the VALU-bound forward of step k)
-    streams = [torch.cuda.Stream(dev) for _ in range(2)]
-    samplers2 = [GaussianSampler(False, fuse="all", backend=a.backend) for _ in range(2)]
-    keep = [None, None]
+    def forward_only(tt, pp, reuse):
+        smp = GaussianSampler(False, fuse="all", backend=a.backend, reuse_samples=reuse)
 
-    def run2(n):
-        for i in range(n):
-            with torch.cuda.stream(streams[i % 2]):
-                samplers2[i % 2].preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
-                keep[i % 2] = samplers2[i % 2].sample((0, 1, 2))
+        def step():
+            smp.preprocess(tt["means"], tt["values"], tt["covariances"], tt["conics"], pp)
+            return smp.sample((0, 1, 2))
+        return smp, step
 
+    # ---------------- untimed pre-heat: a short --steps run must not time a chip that is still ramping ----------------
+    sampler, step = forward_only(t, pts_d, False)
     with torch.no_grad():
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream(dev))
-        run2(max(2, a.warmup))
-        barrier()
         t0 = time.perf_counter()
-        run2(a.steps)
-        barrier()
-        dt2 = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt2], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt2 = float(tmax.item())
-    two_streams = {"ms_per_step": dt2 / a.steps * 1e3, "value": M * world / (dt2 / a.steps),
-                   "what": "the same K steps issued round-robin on two HIP streams (one sampler per stream)"}
-    del keep, samplers2
+        while time.perf_counter() - t0 < PREHEAT_S:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
+        preheat_ms = (time.perf_counter() - t0) * 1e3
+        # ---------------- the headline: K cold steps ----------------
+        dt = timed_steps(step, a.warmup, a.steps)
+        ms_per_step = dt / a.steps * 1e3
+        value = M * world / (dt / a.steps)
+        # ---------------- the same with the samples half of the plan reused ----------------
+        sampler_w, step_w = forward_only(t, pts_d, True)
+        dtw = timed_steps(step_w, a.warmup, a.steps)
+        warm = {"value": M * world / (dtw / a.steps), "ms_per_step": dtw / a.steps * 1e3,
+                "what": "the same K steps with preprocess() handed the same unmodified samples tensor every time: the "
+                        "sorted sample structure is reused, the Gaussians are re-binned and the tile lists rebuilt"}
 
     # ---------------- dominant kernel: HIP events on the launch stream ----------------
-    means, values, conics, samples = sampler._inputs
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.no_grad():
-        plan = sampler._plan
-        S.forward_raw(means, values, conics, samples, 7, plan)
+    def kernel_ms(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
         torch.cuda.synchronize(dev)
         e0.record()
-        for _ in range(a.steps):
-            S.forward_raw(means, values, conics, samples, 7, plan)
+        for _ in range(n):
+            fn()
         e1.record()
         torch.cuda.synchronize(dev)
-    kernel_s = e0.elapsed_time(e1) / a.steps * 1e-3
-    algo_bytes = 24 * N + 36 * M       # fp32, d=2, c=1: 6 floats/Gaussian + (2 in + 7 out) floats/point
-    achieved = algo_bytes / kernel_s
-    roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": measured_traffic(a.workload, a.kappa, plan is not None),
-                "kernel": ("binned_forward_kernel<1,7>" if plan is not None else "dense_forward_kernel<float,2,1,7,4>"),
-                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": algo_bytes}
-    if plan is None:
-        roofline["valu_frac_dense_pairs"] = N * M / kernel_s / VALU_PAIR_PEAK
+        return e0.elapsed_time(e1) / n
+
+    def roofline_of(smp, kappa):
+        means, values, conics, samples = smp._inputs
+        plan = smp._plan
+        with torch.no_grad():
+            k_ms = kernel_ms(lambda: S.forward_raw(means, values, conics, samples, 7, plan), a.steps)
+        algo_bytes = 24 * N + 36 * M       # fp32, d=2, c=1: 6 floats/Gaussian + (2 in + 7 out) floats/point
+        achieved = algo_bytes / (k_ms * 1e-3)
+        traffic, source = measured_traffic(a.workload, kappa, plan is not None)
+        r = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
+             "kernel": ("tile_forward_kernel<1,7>" if plan is not None else "dense_forward_kernel<float,2,1,7,4>"),
+             "kernel_ms": k_ms, "algorithmic_bytes": algo_bytes}
+        if plan is None:
+            r["valu"] = {"pairs": N * M, "frac_of_pair_peak": N * M / (k_ms * 1e-3) / VALU_PAIR_PEAK}
+        else:
+            pr = plan_rows(plan)
+            if pr is not None:
+                instr = pr["wave_rows"] * ROW_VALU_INSTR
+                r["valu"] = {
+                    "pairs": pr["pairs"], "wave_rows": pr["wave_rows"], "pairs_per_point": pr["pairs"] / M,
+                    "frac_of_pair_peak": pr["pairs"] / (k_ms * 1e-3) / VALU_PAIR_PEAK,
+                    "issue_frac": instr / (k_ms * 1e-3) / VALU_ISSUE_PEAK,
+                    "row_loop_floor_ms": pr["wave_rows"] * ROW_NS_UBENCH * 1e-6 / 1024,
+                    "what": "pairs = (point, Gaussian) evaluations of one launch, from the tile headers; issue_frac = "
+                            f"wave_rows x {ROW_VALU_INSTR} VALU instructions (ISA count of the row loop) / kernel time / "
+                            "(1024 SIMDs x 1 instruction per 2 cycles x 2.4 GHz); row_loop_floor_ms = wave_rows x the "
+                            f"{ROW_NS_UBENCH} ns a row costs in the bare row loop at 8 waves/SIMD (tools/ubench/rowloop.hip) "
+                            "/ 1024 SIMDs: what the launch would take if it were only that loop"}
+        return r
+
+    roofline = roofline_of(sampler, a.kappa)
+    binned = sampler._plan is not None
 
     # ---------------- fwd + bwd step (second half of BASELINE.json's metric) ----------------
-    fwd_bwd = None
+    fwd_bwd = roofline_bwd = None
     if not a.no_bwd:
         req = {k: t[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
-
         from pigs_amd.distributed import replicated
+        gouts = None
 
         def train_step():
             # parameter grads are summed over the ranks by ONE all-reduce of a packed [N,6] buffer
             m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
-            sampler.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
-            u, ux, uxx = sampler.sample((0, 1, 2))
+            sampler_w.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
+            u, ux, uxx = sampler_w.sample((0, 1, 2))
             # diffusion residual shape of test_no_mlp.py:144 (u_t replaced by u: same data flow)
             loss = ((u[:, 0] - (uxx[:, 0, 0, 0] + uxx[:, 1, 1, 0])) ** 2).mean() + (ux ** 2).mean()
             return torch.autograd.grad(loss, list(req.values()))
-
-        gouts = None
 
         def sampler_step():
             # the sampler's own share of a training step: incoming gradients supplied, no loss kernels
             nonlocal gouts
             m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
-            sampler.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
-            outs = sampler.sample((0, 1, 2))
+            sampler_w.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
+            outs = sampler_w.sample((0, 1, 2))
             if gouts is None:
                 gouts = tuple(torch.randn_like(o) for o in outs)
             return torch.autograd.grad(outs, list(req.values()), grad_outputs=gouts)
-
-        def timed(fn, n):
-            fn()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            barrier()
-            return (time.perf_counter() - t0) / n * 1e3
 
         def trace_step():
             # the same residual through the fused Hessian-trace output (4 floats per point instead of 7,
             # no slicing of [M,2,2,1] in the loss): extension of the reference API, SURVEY.md 8f-4
             m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
-            sampler.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
-            u, ux, lap = sampler.sample((0, 1, "lap"))
+            sampler_w.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
+            u, ux, lap = sampler_w.sample((0, 1, "lap"))
             loss = ((u - lap) ** 2).mean() + (ux ** 2).mean()
             return torch.autograd.grad(loss, list(req.values()))
 
-        nb = max(1, min(a.steps, 10))
-        fwd_bwd = {"ms_per_step": timed(train_step, nb), "sampler_only_ms_per_step": timed(sampler_step, nb),
-                   "trace_residual_ms_per_step": timed(trace_step, nb), "steps": nb,
-                   "what": "ms_per_step: preprocess + fused fwd(0..2) + torch residual loss + fused bwd; "
-                           "sampler_only: the same without the loss (grad_outputs supplied); "
-                           "trace_residual: the training step with the fused u, grad u, u_xx+u_yy outputs "
-                           "(sample((0, 1, 'lap'))) instead of the full Hessian; "
-                           "hipgraph_replay (1 GPU): the same steps captured once and replayed"
-                           + ("; parameter grads all-reduced as one [N,6] buffer" if dist is not None else "")}
-
-        if dist is None:
+        nb = max(1, min(a.steps, 20))
+        sampler_only_s = timed_steps(sampler_step, 2, nb) / nb
+        fwd_bwd = {"ms_per_step": timed_steps(train_step, 2, nb) / nb * 1e3,
+                   "sampler_only_ms_per_step": sampler_only_s * 1e3,
+                   "trace_residual_ms_per_step": timed_steps(trace_step, 2, nb) / nb * 1e3, "steps": nb,
+                   "value": M * world / sampler_only_s,
+                   "dist_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
+                   "what": "value: points/s of the sampler-only step = preprocess (samples half reused) + fused fwd(0..2) "
+                           "+ fused bwd with the incoming gradients supplied"
+                           + (" + ONE all-reduce of the packed [N,6] parameter gradients over the ranks"
+                              if dist is not None else "")
+                           + "; ms_per_step: the same with a torch residual loss; trace_residual: the training step "
+                           "with the fused u, grad u, u_xx+u_yy outputs (sample((0, 1, 'lap'))) instead of the full "
+                           "Hessian; hipgraph_replay (1 GPU): the same steps captured once and replayed"}
+        # backward kernel alone
+        means, values, conics, samples = sampler_w._inputs
+        plan = sampler_w._plan
+        with torch.no_grad():
+            go = [torch.randn((M,) + (2,) * k + (1,), device=dev) for k in range(3)] + [None, None]
+            kb_ms = kernel_ms(lambda: S.backward_raw(means, values, conics, samples, go, 7, plan), max(5, nb))
+        bwd_bytes = 48 * N + 36 * M
+        roofline_bwd = {"bound": "hbm", "achieved": bwd_bytes / (kb_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": bwd_bytes / (kb_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                        "kernel": ("tile_backward_kernel<1,7> + plan_unpermute_kernel<1>" if plan is not None
+                                   else "dense_backward_kernel"),
+                        "kernel_ms": kb_ms, "algorithmic_bytes": bwd_bytes}
+        if dist is None and not a.no_extras:
             # the same two steps captured ONCE into a hipGraph and replayed (no entry point allocates or
             # synchronises): what a training loop pays when the host is taken out of the way
             try:
@@ -335,15 +407,58 @@ def main():
             except Exception as e:            # report, never lose the bench line over the extra figure
                 fwd_bwd["hipgraph_replay"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+    # ---------------- extras ----------------
+    two_streams = kappa13 = None
+    if not a.no_extras:
+        # the same steps dealt round-robin to two HIP streams (extra figure, not `value`: independent evaluation
+        # steps -- frames of a roll-out -- can overlap the latency-bound plan build of one with the forward of another)
+        streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        samplers2 = [GaussianSampler(False, fuse="all", backend=a.backend, reuse_samples=False) for _ in range(2)]
+        keep = [None, None]
+
+        def run2(n):
+            for i in range(n):
+                with torch.cuda.stream(streams[i % 2]):
+                    samplers2[i % 2].preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
+                    keep[i % 2] = samplers2[i % 2].sample((0, 1, 2))
+
+        with torch.no_grad():
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream(dev))
+            run2(max(2, a.warmup))
+            barrier()
+            t0 = time.perf_counter()
+            run2(a.steps)
+            barrier()
+            dt2 = max_over_ranks(time.perf_counter() - t0)
+        two_streams = {"ms_per_step": dt2 / a.steps * 1e3, "value": M * world / (dt2 / a.steps),
+                       "what": "the same K cold steps issued round-robin on two HIP streams (one sampler per stream)"}
+        del keep, samplers2
+        if abs(a.kappa - 1.3) > 1e-9 and a.workload != "c4":
+            # the reference-like width (report both): kappa = 1.3, ~190 Gaussians within the cut-off
+            gs13, pts13, _, _ = workload(1.3)
+            t13 = {k: v.float().to(dev) for k, v in gs13.items()}
+            s13, step13 = forward_only(t13, pts_d, False)
+            with torch.no_grad():
+                n13 = max(5, a.steps // 4)
+                d13 = timed_steps(step13, 3, n13)
+            r13 = roofline_of(s13, 1.3)
+            kappa13 = {"value": M * world / (d13 / n13), "ms_per_step": d13 / n13 * 1e3, "steps": n13,
+                       "kernel_ms": r13["kernel_ms"], "frac": r13["frac"], "valu": r13.get("valu")}
+
     line = {
         "metric": "sample-points/sec (fwd + 1st + 2nd derivatives, fused)", "value": value,
         "unit": "sample-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if a.workload == "c4" else "weak",
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded lattice Gaussians, regular sample grid)",
         "config": {"workload": f"{a.workload}: {N} Gaussians x {side}x{side} grid, {rows} rows x {side} points per "
                                f"GPU, d=2, c=1, kappa={a.kappa}, orders 0-2", "gaussians": N, "points_per_gpu": M,
-                   "kappa": a.kappa, "path": "binned" if sampler._plan is not None else "dense", "step": "preprocess + fused forward (orders 0..2)"},
-        "roofline": roofline, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
+                   "kappa": a.kappa, "path": "binned" if binned else "dense",
+                   "step": "preprocess (cold: nothing reused) + fused forward (orders 0..2)"},
+        "preheat_ms": preheat_ms, "value_warm_plan": warm["value"], "warm_plan": warm,
+        "roofline": roofline, "roofline_bwd": roofline_bwd, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
+        "kappa_1_3": kappa13,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(gs, pts)

@@ -81,8 +81,11 @@ def build_covariances(s, t):
 def build_full_covariances(s, t):
     """(covariances [N,2,2], conics [N,2,2]); gaussians.py:163-183."""
     cov, con = build_covariances(s, t)
-    idx = torch.tensor([0, 1, 1, 2], device=cov.device)
-    return cov[:, idx].reshape(-1, 2, 2), con[:, idx].reshape(-1, 2, 2)
+    # no index tensor: torch.tensor(..., device=...) is a pageable host-to-device copy on every call
+    # and cannot be captured into a hipGraph
+    def full(f):
+        return torch.stack((f[:, 0], f[:, 1], f[:, 1], f[:, 2]), dim=-1).reshape(-1, 2, 2)
+    return full(cov), full(con)
 
 
 def _upper(m):

@@ -265,6 +265,10 @@ class GaussianSampler:
     of the plan is rebuilt -- the reference's roll-out binds new Gaussians to a fixed grid every
     step (main_pn.py:317-324).  ``False`` rebuilds everything every time.
 
+    ``unpinned_aggregate`` (extension, keyword only): ``preprocess_aggregate`` / ``aggregate_neighbors``
+    follow this repository's own definition (the reference's is not visible: parity unpinned) and
+    warn once per process unless this is set.
+
     ``fuse`` (extension, keyword only) controls how many derivative orders one launch computes:
     ``"auto"`` -- the first ``sample_*`` call after a ``preprocess`` computes orders 0..2 in one
     launch when the problem is small enough to be launch-bound (M <= 65536), otherwise only the
@@ -276,9 +280,10 @@ class GaussianSampler:
     BINNED_AUTO_MIN_PAIRS = 1 << 26     # dense: ~1.2e12 pairs/s; the plan costs ~32 us to build
 
     _warned_samples_grad = False
+    _warned_aggregate = False
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
-                 reuse_samples=True):
+                 reuse_samples=True, unpinned_aggregate=False):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):
@@ -293,6 +298,7 @@ class GaussianSampler:
         if self.q_max_order3 < self.q_max:
             raise ValueError("q_max_order3 must not be below q_max")
         self.reuse_samples = bool(reuse_samples)
+        self.unpinned_aggregate = bool(unpinned_aggregate)
         self._plan3 = None
         self._inputs = None
         self._plan = None
@@ -460,6 +466,14 @@ class GaussianSampler:
         """Build the Gaussian <-> Gaussian neighbour structure for :meth:`aggregate_neighbors`
         (model_pn.py:257).  Semantics are this repo's own (parity unpinned): pigs_amd/aggregate.py."""
         from . import aggregate
+        if not self.unpinned_aggregate and not GaussianSampler._warned_aggregate:
+            GaussianSampler._warned_aggregate = True
+            import warnings
+            warnings.warn("GaussianSampler.preprocess_aggregate / aggregate_neighbors: the arithmetic of these two "
+                          "methods exists only in the reference's absent CUDA source; what runs here is this "
+                          "repository's own definition (pigs_amd/aggregate.py, DESIGN.md) -- a model trained with "
+                          "the reference will not reproduce through it.  Pass unpinned_aggregate=True to "
+                          "GaussianSampler to acknowledge.", stacklevel=2)
         means, _, conics, _ = self._require_inputs()
         self._neighbors = aggregate.neighbor_structure(means.detach(), conics.detach(), self.q_max)
 

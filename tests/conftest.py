@@ -15,8 +15,10 @@ def pytest_configure(config):
 
 
 def golden_files():
-    """The sampler fixtures (ref_build_covariances.npz pins the covariance builder: tests/test_covariances.py)."""
-    return sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("ref_build_"))
+    """The sampler fixtures (ref_build_covariances.npz pins the covariance builder: tests/test_covariances.py;
+    model_pn_trace_*.npz are the model call traces: tests/test_model_trace_gpu.py)."""
+    return sorted(f for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and not f.startswith("ref_build_") and not f.startswith("model_pn_trace_"))
 
 
 @pytest.fixture(scope="session")

@@ -102,3 +102,32 @@ def test_torch_dense_port_matches_reference(name):
     out = dense_torch.forward(*t, orders=(0, 1, 2), chunk=100)
     for o in range(3):
         assert rel(out[o].numpy(), z[f"out{o}_f64"]) < 1e-12
+
+
+def test_model_trace_fixtures_match_c_oracle():
+    """The model_pn.Model call traces (tools/gen_model_trace.py: recorded with a torch float64 oracle inside
+    the reference's own training loop) against the independent C restatement: outputs of every
+    order and the parameter gradients of every back-propagated record."""
+    import glob
+    from oracle import c_oracle
+    files = sorted(glob.glob(os.path.join(GOLDEN, "model_pn_trace_*.npz")))
+    assert len(files) >= 3
+    checked = 0
+    for f in files:
+        z = np.load(f)
+        for k in range(int(z["n_records"])):
+            calls = [int(o) for o in z[f"r{k}_calls"]]
+            args = [z[f"r{k}_{n}"].astype(np.float64) for n in ("means", "conics", "values", "samples")]
+            exp = c_oracle.forward(*args, orders=tuple(calls))
+            for o in calls:
+                want = z[f"r{k}_out{o}"]
+                assert np.abs(exp[o] - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-300), (f, k, o)
+            gouts = {o: z[f"r{k}_gout{o}"].astype(np.float64) for o in range(4) if f"r{k}_gout{o}" in z.files}
+            if gouts:
+                gm, gc, gv = c_oracle.backward(*args, gouts)
+                for got, name in ((gm, "means"), (gv, "values"), (gc, "conics")):
+                    want = z[f"r{k}_g{name}"].reshape(got.shape)
+                    # the recorded gradient left the float64 oracle through a float32 cast
+                    assert np.abs(got - want).max() <= 3e-7 * np.abs(want).max(), (f, k, name)
+                checked += 1
+    assert checked >= 10
