@@ -904,7 +904,12 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         nmax = hd[4] > nmax ? hd[4] : nmax;
         for (uint32_t base = 0; base < nmax; base += GROUP_CAP) {
             const int rows = (int)(nmax - base < GROUP_CAP ? nmax - base : GROUP_CAP);
-            chunk(rows, [&](int p) { return base + p < ng ? gl[base + p] : pv.N; });
+            // the entry is loaded whether or not it lies inside the list (the slab has the room, and
+            // the load then does not wait for the header): one dependent round trip less per tile
+            chunk(rows, [&](int p) {
+                const uint32_t e = gl[base + p < pv.list_cap ? base + p : 0u];
+                return base + p < ng ? e : pv.N;
+            });
         }
     } else {
         const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
@@ -917,7 +922,23 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
             }
         }
     }
-    if (valid) fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+    if (valid) {
+#ifdef PIGS_FWD_WT_HESSIAN
+        // the Hessian rows are whole 16-byte quads per point (whole 128-byte lines per 8 points of a grid
+        // row): written through (sc1), they leave the L2 as they are stored instead of staying dirty
+        // until the end-of-kernel write-back
+        if constexpr (C == 1 && (MASK & ORD2) != 0) {
+            if (o2) {
+                using L2_ = FwdLayout<2, C, MASK>;
+                f4v h = {acc[L2_::O2], acc[L2_::O2 + 1], acc[L2_::O2 + 1], acc[L2_::O2 + 2]};
+                float* dst = o2 + (size_t)sp.m * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(h) : "memory");
+            }
+            fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, nullptr, o3);
+        } else
+#endif
+        fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -932,15 +953,17 @@ struct TileLds {
 };
 constexpr uint32_t ZERO_REC_OFF = TILE_POINTS * 32u;
 
-// splits the step's masks; returns the padded row count (a multiple of UNROLL)
+// splits the step's masks; returns the padded row count (a multiple of UNROLL); rank[g] = position of
+// this lane's entry in group g's list (meaningful where its mask bit is set)
 template <int UNROLL>
-__device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane) {
+__device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane, int* rank) {
     int cnt[4], rows = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const bool bit = gm >> g & 1u;
         const uint64_t m = __ballot(bit);
-        if (bit) lds.list[g][lanes_below(m)] = (uint32_t)lane * 32u;
+        rank[g] = lanes_below(m);
+        if (bit) lds.list[g][rank[g]] = (uint32_t)lane * 32u;
         cnt[g] = __builtin_popcountll(m);
         rows = cnt[g] > rows ? cnt[g] : rows;
     }
@@ -953,57 +976,111 @@ __device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane) {
 
 // ------------------------------------------------------------------------------------------
 // Backward: the same tile / list structure.  Every (row, Gaussian) pair of a step yields
-// NV = 5 + c per-lane contributions that must be summed over the row's 16 points; the sums of the
-// (up to four) rows that work on the same Gaussian meet in an LDS table indexed by the entry's
-// slot (ds_add_f32), which is flushed once per step with one atomic per entry and value into
-// gacc[k][j] (entries follow the sorted order, so consecutive lanes hit near-consecutive
-// addresses); plan_unpermute_kernel writes the caller's layout.
+// NV = 5 + c per-lane contributions that must be summed over the row's 16 points.  The row sums
+// are written -- plain stores, no read-modify-write: a (group, list position) pair is met once --
+// into an LDS table indexed by group and list position; at the end of the step every lane, which
+// knows the positions of its own entry in the (up to four) group lists from the split, adds its
+// rows of the table and flushes ONE atomic per entry and value into gacc[k][j] (entries follow the
+// sorted order, so consecutive lanes hit near-consecutive addresses); plan_unpermute_kernel writes
+// the caller's layout.  (LDS float atomics into a per-entry table took 44 LDS cycles per
+// instruction here: the kernel ran at the LDS's pace.)
 // ------------------------------------------------------------------------------------------
+template <int NV>
 struct TileLdsBwd {
+    static constexpr int S = NV <= 6 ? 6 : 8;        // floats per table row (8-byte aligned)
     TileLds t;
-    float sums[TILE_POINTS + 1][8];   // per-slot reduced contributions; row 64 collects the padding rows
+    float sums[4][TILE_POINTS + 4][S];               // [group][list position]: reduced contributions
 };
 
-// sum over the 16 lanes of a row, in every lane of it, for G values at once: the chains are
-// independent and interleaved so that one s_nop covers the DPP wait states of all of them
-#define PIGS_ROW1(MOD, R) "v_add_f32_dpp " R ", " R ", " R " " MOD " row_mask:0xf bank_mask:0xf\n\t"
-#define PIGS_ROW3(MOD) PIGS_ROW1(MOD, "%0") PIGS_ROW1(MOD, "%1") PIGS_ROW1(MOD, "%2")
-#define PIGS_ROW4(MOD) PIGS_ROW3(MOD) PIGS_ROW1(MOD, "%3")
-template <int G>
-__device__ __forceinline__ void row_sum_group(float* y) {
-    static_assert(G == 3 || G == 4, "groups of three or four");
-    if constexpr (G == 3)
-        asm volatile("s_nop 1\n\t" PIGS_ROW3("quad_perm:[1,0,3,2]") PIGS_ROW3("quad_perm:[2,3,0,1]")
-                     PIGS_ROW3("row_half_mirror") PIGS_ROW3("row_mirror") "s_nop 1"
-                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]));
+// Row sums of FOUR wave-rows at once by a transposing fold.  Input: v[u][k], u = 0..3 (four consecutive
+// list rows), k < NV, each to be summed over the 16 lanes of every DPP row.  Two folding levels merge
+// the four u of one k into ONE register while they halve the lanes twice: bank_mask lets a DPP add
+// write only some of a row's four banks (4 lanes each), so two adds build one merged register --
+//   level A (row_ror:8, lanes i <-> i^8):       banks {0,1} <- v[u0] ,  banks {2,3} <- v[u1]
+//   level B (row_half_mirror, i <-> 7-i of 8):   banks {0,2} <- first ,  banks {1,3} <- second
+// -- then two quad steps finish the sum inside each bank.  6 + 2 instructions per k and four rows
+// = 2 NV per row instead of 4 NV.  Afterwards every lane of bank b of a DPP row holds, in z[k], the
+// sum over that row's 16 lanes of v[SIGMA(b)][k], SIGMA = {0, 2, 1, 3}.
+#define PIGS_FOLD_A(OUT, X, Y)                                                            \
+    "v_add_f32_dpp " OUT ", " X ", " X " row_ror:8 row_mask:0xf bank_mask:0x3\n\t"        \
+    "v_add_f32_dpp " OUT ", " Y ", " Y " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+#define PIGS_FOLD_B(OUT, X, Y)                                                            \
+    "v_add_f32_dpp " OUT ", " X ", " X " row_half_mirror row_mask:0xf bank_mask:0x5\n\t"  \
+    "v_add_f32_dpp " OUT ", " Y ", " Y " row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+// two values k at a time: their chains are interleaved, so that one s_nop at the head covers the two
+// wait states a DPP read needs behind the VALU write of its source
+__device__ __forceinline__ void fold4_pair(float& z0, float& z1, float a0, float a1, float a2, float a3, float b0,
+                                           float b1, float b2, float b3) {
+    float t0, t1, t2, t3;
+    asm volatile("s_nop 1\n\t"
+                 PIGS_FOLD_A("%2", "%6", "%7") PIGS_FOLD_A("%3", "%8", "%9")
+                 PIGS_FOLD_A("%4", "%10", "%11") PIGS_FOLD_A("%5", "%12", "%13")
+                 PIGS_FOLD_B("%0", "%2", "%3") PIGS_FOLD_B("%1", "%4", "%5")
+                 : "=&v"(z0), "=&v"(z1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+__device__ __forceinline__ void fold4_single(float& z0, float a0, float a1, float a2, float a3) {
+    float t0, t1;
+    asm volatile("s_nop 1\n\t"
+                 PIGS_FOLD_A("%1", "%3", "%4") PIGS_FOLD_A("%2", "%5", "%6")
+                 "s_nop 1\n\t"
+                 PIGS_FOLD_B("%0", "%1", "%2")
+                 : "=&v"(z0), "=&v"(t0), "=&v"(t1)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+#define PIGS_QUAD1(MOD, R) "v_add_f32_dpp " R ", " R ", " R " " MOD " row_mask:0xf bank_mask:0xf\n\t"
+#define PIGS_QUAD6(MOD) PIGS_QUAD1(MOD, "%0") PIGS_QUAD1(MOD, "%1") PIGS_QUAD1(MOD, "%2") PIGS_QUAD1(MOD, "%3") \
+    PIGS_QUAD1(MOD, "%4") PIGS_QUAD1(MOD, "%5")
+template <int NV>
+__device__ __forceinline__ void quad_sums(float* z) {
+    static_assert(NV == 6 || NV == 7, "5 + c values");
+    if constexpr (NV == 6)
+        asm volatile("s_nop 1\n\t" PIGS_QUAD6("quad_perm:[1,0,3,2]") PIGS_QUAD6("quad_perm:[2,3,0,1]") "s_nop 1"
+                     : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]));
     else
-        asm volatile("s_nop 1\n\t" PIGS_ROW4("quad_perm:[1,0,3,2]") PIGS_ROW4("quad_perm:[2,3,0,1]")
-                     PIGS_ROW4("row_half_mirror") PIGS_ROW4("row_mirror") "s_nop 1"
-                     : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+        asm volatile("s_nop 1\n\t" PIGS_QUAD6("quad_perm:[1,0,3,2]") PIGS_QUAD1("quad_perm:[1,0,3,2]", "%6")
+                     PIGS_QUAD6("quad_perm:[2,3,0,1]") PIGS_QUAD1("quad_perm:[2,3,0,1]", "%6") "s_nop 1"
+                     : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]));
 }
 
+// rows: a multiple of 4 (split_step<4> pads the lists with the all-zero record; the sums of such rows
+// land behind the lists' ends in the table and are never read)
 template <int C, int MASK>
-__device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 2, C, MASK>& G, TileLdsBwd& lds,
-                                              int rows, int lane) {
+__device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 2, C, MASK>& G,
+                                              TileLdsBwd<BwdLayout<2, C>::N>& lds, int rows, int lane) {
     using BL = BwdLayout<2, C>;
     constexpr int NV = BL::N;
+    constexpr int S = TileLdsBwd<NV>::S;
     const char* base = (const char*)&lds.t.rec[0][0];
-    const uint32_t* lst = lds.t.list[lane >> 4];
-    const bool leader = (lane & 15) == 0;
-    for (int k = 0; k < rows; ++k) {
-        const uint32_t off = lst[k];
-        const Rec r = make_rec(*(const float4*)(base + off), *(const float4*)(base + off + 16));
-        float part[NV];
+    const int g = lane >> 4;
+    const uint32_t* lst = lds.t.list[g];
+    const int bank = (lane >> 2) & 3;
+    const int sigma = ((bank & 1) << 1) | (bank >> 1);      // {0, 2, 1, 3}: the list row whose sums this lane's bank ends up with
+    const bool leader = (lane & 3) == 0;
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+        float part[4][NV];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) part[q] = 0.f;
-        bwd_accumulate<float, 2, C, MASK, (MASK & ORD3) != 0>(part, s, r.mu, r.con, r.v, G);
-        row_sum_group<3>(part);
-        if constexpr (NV == 6) row_sum_group<3>(part + 3);
-        else row_sum_group<4>(part + 3);
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t off = lst[k0 + u];
+            const Rec r = make_rec(*(const float4*)(base + off), *(const float4*)(base + off + 16));
+#pragma unroll
+            for (int q = 0; q < NV; ++q) part[u][q] = 0.f;
+            bwd_accumulate<float, 2, C, MASK, (MASK & ORD3) != 0>(part[u], s, r.mu, r.con, r.v, G);
+        }
+        float z[8];
+#pragma unroll
+        for (int q = 0; q + 1 < NV; q += 2)
+            fold4_pair(z[q], z[q + 1], part[0][q], part[1][q], part[2][q], part[3][q], part[0][q + 1], part[1][q + 1],
+                       part[2][q + 1], part[3][q + 1]);
+        if constexpr (NV & 1) {
+            fold4_single(z[NV - 1], part[0][NV - 1], part[1][NV - 1], part[2][NV - 1], part[3][NV - 1]);
+            z[NV] = 0.f;
+        }
+        quad_sums<NV>(z);
         if (leader) {
-            float* dst = lds.sums[off >> 5];
+            float2* dst = (float2*)lds.sums[g][k0 + sigma];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) __hip_atomic_fetch_add(&dst[q], part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int q = 0; q < S; q += 2) dst[q / 2] = make_float2(z[q], z[q + 1]);
         }
     }
 }
@@ -1018,12 +1095,13 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     const float* __restrict__ G2p, const float* __restrict__ G3p) {
     using BL = BwdLayout<2, C>;
     constexpr int NV = BL::N;
-    __shared__ TileLdsBwd lds_all[4];
+    constexpr int S = TileLdsBwd<NV>::S;
+    __shared__ TileLdsBwd<NV> lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
     if (tile >= sv.ntiles) return;
-    TileLdsBwd& lds = lds_all[wave];
+    TileLdsBwd<NV>& lds = lds_all[wave];
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
     const bool valid = m < sv.M;
     const SPoint sp = sv.spts[valid ? m : sv.M - 1];
@@ -1040,23 +1118,34 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
         }
     }
     if (lane < 2) lds.t.rec[TILE_POINTS][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) lds.sums[lane][q] = 0.f;
     for_each_step(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
         const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
         wave_lds_fence();
         lds.t.rec[lane][0] = A;
         lds.t.rec[lane][1] = B;
-        const int rows = split_step<1>(lds.t, gm, lane);
+        int rank[4];
+        const int rows = split_step<4>(lds.t, gm, lane, rank);
         wave_lds_fence();
         backward_rows<C, MASK>(s, G, lds, rows, lane);
         wave_lds_fence();
-        if (have && gm != 0u) {
+        if (have && gm != 0u) {               // this lane's entry: its rows of the table, one atomic per value
+            float sum[S];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], lds.sums[lane][q]);
+            for (int q = 0; q < S; ++q) sum[q] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (gm >> g & 1u) {
+                    const float2* src = (const float2*)lds.sums[g][rank[g]];
+#pragma unroll
+                    for (int q = 0; q < S; q += 2) {
+                        const float2 v = src[q / 2];
+                        sum[q] += v.x; sum[q + 1] += v.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], sum[q]);
         }
-#pragma unroll
-        for (int q = 0; q < NV; ++q) lds.sums[lane][q] = 0.f;
     });
 }
 
