@@ -148,6 +148,43 @@ size_t pigs_plan_error_offset(void);
  * Returns PIGS_ERR_UNSUPPORTED for sizes the binned path does not take. */
 int pigs_plan_layout_info(int64_t N, int64_t M, int c, int64_t info[6]);
 
+/*
+ * preprocess_aggregate() / aggregate_neighbors() -- GaussianSampler methods of the reference
+ * (model_pn.py:257-264; test_neighbor_aggregation.py:75-98).  PARITY UNPINNED: their arithmetic exists
+ * only in the reference's absent CUDA source; these entry points implement this repository's own
+ * definition (DESIGN.md "aggregate_neighbors"; pigs_amd/csrc/aggregate.hip), d = 2, float32 / float64:
+ *   neighbours of i = { j : (mu_i - mu_j)^T C_j (mu_i - mu_j) <= q_max };  a_ij = softmax_j <queries_i, keys_j> / sqrt(K);
+ *   out_i = sum_j a_ij (transform features_j + distance_transform [e_ij ; g_ij e_ij]),  e_ij = Fourier embedding
+ *   of mu_j - mu_i with `frequencies` (E = 4F + 1 entries), g_ij = exp(-q_ij / 2).
+ * The neighbour relation is kept as index lists -- `cap` int32 slots per Gaussian, by rows (the j of an
+ * i) and by columns (the i that hold a j) -- never as an [N, N, ...] tensor.
+ *
+ * pigs_aggregate_lists: counts [N] and lists [N][cap] by rows and by columns; *overflow (int32, zeroed
+ *   by the caller) is set when a list did not fit `cap` (it is then truncated).
+ * pigs_aggregate_forward: out [N][L], and for the backward lse [N] (log-sum-exp of the scaled scores)
+ *   and acc [N][L + 2E] = (sum_j a_ij features_j ; sum_j a_ij [e_ij ; g_ij e_ij]).
+ * pigs_aggregate_backward: given dacc [N][L + 2E] = gout [transform | distance_transform] and
+ *   D [N] = <dacc_i, acc_i> (plain GEMMs, left to the caller, as are d transform = gout^T acc[:, :L] and
+ *   d distance_transform = gout^T acc[:, L:]), writes g_features [N][L], g_queries [N][K], g_keys [N][K]
+ *   and g_freq_rows [N][F] (summed over the rows by the caller: no atomics, deterministic).
+ */
+int pigs_aggregate_lists(int dtype, int64_t N, int64_t cap, const void* means, const void* conics, double q_max,
+                         int32_t* row_counts, int32_t* row_lists, int32_t* col_counts, int32_t* col_lists,
+                         int32_t* overflow, void* stream);
+
+int pigs_aggregate_forward(int dtype, int64_t N, int64_t cap, int L, int K, int F,
+                           const void* means, const void* conics, const int32_t* row_counts, const int32_t* row_lists,
+                           const void* features, const void* transform, const void* queries, const void* keys,
+                           const void* frequencies, const void* distance_transform,
+                           void* out, void* lse, void* acc, void* stream);
+
+int pigs_aggregate_backward(int dtype, int64_t N, int64_t cap, int L, int K, int F,
+                            const void* means, const void* conics, const int32_t* row_counts, const int32_t* row_lists,
+                            const int32_t* col_counts, const int32_t* col_lists,
+                            const void* features, const void* queries, const void* keys, const void* frequencies,
+                            const void* lse, const void* dacc, const void* D,
+                            void* g_features, void* g_queries, void* g_keys, void* g_freq_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,24 @@ int dense_dispatch(bool backward, const SampleArgs& a, hipStream_t stream);
 int covariances_dispatch(bool backward, int dtype, int64_t N, const void* scaling, const void* transform,
                          const void* a, const void* b, void* o0, void* o1, hipStream_t stream);
 
+// aggregate.hip
+struct AggregateArgs {
+    int dtype;
+    int64_t N, cap;
+    int L, K, F;
+    const void *means, *conics;
+    const int32_t *row_counts, *row_lists, *col_counts, *col_lists;
+    const void *features, *transform, *queries, *keys, *frequencies, *distance_transform;
+    void *out, *lse, *acc;                         // forward outputs (the backward reads lse)
+    const void *dacc, *D;                          // backward inputs
+    void *g_features, *g_queries, *g_keys, *g_freq_rows;
+};
+int aggregate_lists(int dtype, int64_t N, int64_t cap, const void* means, const void* conics, double q_max,
+                    int32_t* row_counts, int32_t* row_lists, int32_t* col_counts, int32_t* col_lists, int32_t* overflow,
+                    hipStream_t stream);
+int aggregate_forward(const AggregateArgs& a, hipStream_t stream);
+int aggregate_backward(const AggregateArgs& a, hipStream_t stream);
+
 // plan.hip
 size_t samples_workspace_bytes(int64_t M);
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c);

@@ -307,9 +307,17 @@ template <int D, int C> struct BwdLayout {
 // to zero the polynomial factors can overflow (p^4 C ~ 1e38 for sigma ~ 1e-4 of the distance)
 // and 0 * inf would poison the sums; such a pair contributes exactly nothing, so its x and p are
 // zeroed (v_exp_f32 flushes denormals: g is either above 1e-38 or exactly 0).
-template <typename T, int D, int C, int MASK, bool FAR_GUARD = false>
+//
+// FACTORED (D = 2, C = 1 only): what depends on the Gaussian alone is left out of the per-pair work
+// and applied once per Gaussian by the caller (plan_unpermute_kernel):
+//   acc[MU]  = sum_m g (A x - dA)                    -> dL/dmu = v C acc[MU]      (A p - C dA = C (A x - dA))
+//   acc[CON] = sum_m g (-A x x^T / 2 + dA x^T + E)   -> dL/dC  = v acc[CON]
+//   acc[VAL] = sum_m g F                             (unchanged)
+// 38 instead of 46 instructions per pair for orders 0..2.
+template <typename T, int D, int C, int MASK, bool FAR_GUARD = false, bool FACTORED = false>
 __device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, const T* con, const T* v,
                                                const Gsym<T, D, C, MASK>& G) {
+    static_assert(!FACTORED || (D == 2 && C == 1), "the factored form is written for d = 2, c = 1");
     using L = BwdLayout<D, C>;
     Pair<T, D> pr;
     pr.eval(s, mu, con);
@@ -408,6 +416,19 @@ __device__ __forceinline__ void bwd_accumulate(T* acc, const T* s, const T* mu, 
                 Exy = fma_<T>(v[ch], exy, Exy);
                 Eyy = fma_<T>(v[ch], eyy, Eyy);
             }
+        }
+        if constexpr (FACTORED) {
+            // r = -A x / 2;  A x - dA = -(2 r + dA);  conic terms: x_k (r_k + dA_k) + E_kk, and for the
+            // off-diagonal x_1 (2 r_0 + dA_0) + dA_1 x_0 + E_01 = -x_1 mx + dA_1 x_0 + E_01
+            const T hA = T(-0.5) * A;
+            const T rx = hA * dx, ry = hA * dy;
+            const T mx = fma_<T>(T(-2), rx, -dAx), my = fma_<T>(T(-2), ry, -dAy);
+            acc[L::MU + 0] = fma_<T>(g, mx, acc[L::MU + 0]);
+            acc[L::MU + 1] = fma_<T>(g, my, acc[L::MU + 1]);
+            acc[L::CON + 0] = fma_<T>(g, fma_<T>(rx + dAx, dx, Exx), acc[L::CON + 0]);
+            acc[L::CON + 1] = fma_<T>(g, fma_<T>(-mx, dy, fma_<T>(dAy, dx, Exy)), acc[L::CON + 1]);
+            acc[L::CON + 2] = fma_<T>(g, fma_<T>(ry + dAy, dy, Eyy), acc[L::CON + 2]);
+            return;
         }
         const T g_ = g;
         const T g = (C == 1) ? g_ * v[0] : g_;          // weight of the mean / conic terms

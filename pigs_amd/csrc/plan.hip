@@ -26,7 +26,7 @@
 #define PIGS_FWD_UNROLL 2     // list rows evaluated per loop iteration
 #endif
 #ifndef PIGS_BWD_WAVES
-#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to
+#define PIGS_BWD_WAVES 6      // waves per SIMD the register budget of the backward's narrow variants is held to
 #endif
 #ifndef PIGS_TRAV_STEPS
 #define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
@@ -725,23 +725,24 @@ __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
     return r;
 }
 
-// Walks a tile's list (or its ranges): `step(idx, gm, have)` for every 64 entries.
-template <typename Step>
+// Walks a tile's list (or its ranges): `step(idx, gm, have)` for every STEP entries (lane = entry; the
+// lanes from STEP on hold none).
+template <int STEP, typename Step>
 __device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step) {
     const uint32_t hdr = pv.hdr[(size_t)tile * TILE_HDR_WORDS];
     const uint32_t count = hdr & TILE_COUNT_MASK;
     const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
     if ((hdr >> TILE_MODE_SHIFT) == TILE_MODE_LIST) {
-        for (uint32_t e0 = 0; e0 < count; e0 += 64) {
-            const bool have = e0 + (uint32_t)lane < count;
+        for (uint32_t e0 = 0; e0 < count; e0 += STEP) {
+            const bool have = lane < STEP && e0 + (uint32_t)lane < count;
             const uint32_t e = have ? slab[e0 + lane] : 0u;
             step(e & LIST_IDX_MASK, e >> LIST_IDX_BITS, have);
         }
     } else {
         for (uint32_t r = 0; r < count; ++r) {
             const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
-            for (uint32_t o = 0; o < len; o += 64) {
-                const bool have = o + (uint32_t)lane < len;
+            for (uint32_t o = 0; o < len; o += STEP) {
+                const bool have = lane < STEP && o + (uint32_t)lane < len;
                 step(have ? j0 + o + (uint32_t)lane : j0, have ? 0xFu : 0u, have);
             }
         }
@@ -946,12 +947,17 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
 // split into four per-row index lists holding LDS byte offsets, padded with the offset of an
 // all-zero record to the longest of the four.
 // ------------------------------------------------------------------------------------------
+#ifndef PIGS_BWD_STEP
+#define PIGS_BWD_STEP 32      // entries per step of the backward: its LDS (records, lists, sums table) scales with it
+#endif
+constexpr int BWD_STEP = PIGS_BWD_STEP;
+static_assert(BWD_STEP == 32 || BWD_STEP == 64, "entries per step");
 constexpr int LIST_PAD = 8;
 struct TileLds {
-    float4 rec[TILE_POINTS + 1][2];            // slot 64: the all-zero record (v = 0: contributes nothing)
-    uint32_t list[4][TILE_POINTS + LIST_PAD];  // byte offsets into rec
+    float4 rec[BWD_STEP + 1][2];            // slot BWD_STEP: the all-zero record (v = 0: contributes nothing)
+    uint32_t list[4][BWD_STEP + LIST_PAD];  // byte offsets into rec
 };
-constexpr uint32_t ZERO_REC_OFF = TILE_POINTS * 32u;
+constexpr uint32_t ZERO_REC_OFF = BWD_STEP * 32u;
 
 // splits the step's masks; returns the padded row count (a multiple of UNROLL); rank[g] = position of
 // this lane's entry in group g's list (meaningful where its mask bit is set)
@@ -989,7 +995,7 @@ template <int NV>
 struct TileLdsBwd {
     static constexpr int S = NV <= 6 ? 6 : 8;        // floats per table row (8-byte aligned)
     TileLds t;
-    float sums[4][TILE_POINTS + 4][S];               // [group][list position]: reduced contributions
+    float sums[4][BWD_STEP + 4][S];                  // [group][list position]: reduced contributions
 };
 
 // Row sums of FOUR wave-rows at once by a transposing fold.  Input: v[u][k], u = 0..3 (four consecutive
@@ -1065,7 +1071,7 @@ __device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 
             const Rec r = make_rec(*(const float4*)(base + off), *(const float4*)(base + off + 16));
 #pragma unroll
             for (int q = 0; q < NV; ++q) part[u][q] = 0.f;
-            bwd_accumulate<float, 2, C, MASK, (MASK & ORD3) != 0>(part[u], s, r.mu, r.con, r.v, G);
+            bwd_accumulate<float, 2, C, MASK, (MASK & ORD3) != 0, C == 1>(part[u], s, r.mu, r.con, r.v, G);
         }
         float z[8];
 #pragma unroll
@@ -1087,7 +1093,8 @@ __device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 
 
 template <int C, int MASK>
 constexpr int bwd_waves() {      // the widest gradient sets get 3 waves (168 VGPRs): no spills
-    return ((C == 2 && (MASK == 7 || MASK == 8 || MASK == 15)) || (C == 1 && MASK == 15)) ? 3 : PIGS_BWD_WAVES;
+    return ((C == 2 && (MASK == 7 || MASK == 8 || MASK == 15)) || (C == 1 && MASK == 15)) ? 3
+           : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1 || MASK == 2)) ? PIGS_BWD_WAVES : 4;
 }
 template <int C, int MASK>
 __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
@@ -1117,12 +1124,14 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
             G.g3[0][ch] = G.g3[1][ch] = G.g3[2][ch] = G.g3[3][ch] = 0.f;
         }
     }
-    if (lane < 2) lds.t.rec[TILE_POINTS][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for_each_step(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
+    if (lane < 2) lds.t.rec[BWD_STEP][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for_each_step<BWD_STEP>(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
         const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
         wave_lds_fence();
-        lds.t.rec[lane][0] = A;
-        lds.t.rec[lane][1] = B;
+        if (lane < BWD_STEP) {
+            lds.t.rec[lane][0] = A;
+            lds.t.rec[lane][1] = B;
+        }
         int rank[4];
         const int rows = split_step<4>(lds.t, gm, lane, rank);
         wave_lds_fence();
@@ -1162,6 +1171,17 @@ __global__ __launch_bounds__(256) void plan_unpermute_kernel(PlanView pv, float*
     for (int k = 0; k < BL::N; ++k) {
         v[k] = pv.gacc[(size_t)k * pv.N + j];
         pv.gacc[(size_t)k * pv.N + j] = 0.f;       // leave the scratch zeroed for the next backward
+    }
+    if constexpr (C == 1) {
+        // the backward accumulates the factored sums (pair_math.h, FACTORED): finish them with the
+        // Gaussian's own conic and value
+        const float4 A = pv.rec[2 * j], B = pv.rec[2 * j + 1];
+        const float a = A.z, b = A.w, c = B.x, val = B.y;
+        const float sx = v[BL::MU + 0], sy = v[BL::MU + 1];
+        v[BL::MU + 0] = val * (a * sx + b * sy);
+        v[BL::MU + 1] = val * (b * sx + c * sy);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[BL::CON + k] *= val;
     }
     g_means[2 * n] = v[BL::MU + 0];
     g_means[2 * n + 1] = v[BL::MU + 1];

@@ -475,7 +475,11 @@ class GaussianSampler:
                           "the reference will not reproduce through it.  Pass unpinned_aggregate=True to "
                           "GaussianSampler to acknowledge.", stacklevel=2)
         means, _, conics, _ = self._require_inputs()
-        self._neighbors = aggregate.neighbor_structure(means.detach(), conics.detach(), self.q_max)
+        if means.shape[1] != 2:
+            raise NotImplementedError("aggregate_neighbors is implemented for d = 2")
+        self._neighbors = aggregate.NeighborLists(means, conics, self.q_max)
+        if self.debug:
+            self._neighbors.check()
 
     def aggregate_neighbors(self, features, transform, queries, keys, frequencies, distance_transform):
         """[N, L] attention-weighted neighbour messages (model_pn.py:262-264); differentiable wrt all
@@ -483,6 +487,4 @@ class GaussianSampler:
         from . import aggregate
         if getattr(self, "_neighbors", None) is None:
             raise RuntimeError("preprocess_aggregate() must be called before aggregate_neighbors()")
-        mask, delta, g = self._neighbors
-        return aggregate.aggregate(mask, delta.to(features.dtype), g.to(features.dtype), features, transform,
-                                   queries, keys, frequencies, distance_transform)
+        return aggregate.aggregate(self._neighbors, features, transform, queries, keys, frequencies, distance_transform)

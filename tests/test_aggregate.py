@@ -1,12 +1,12 @@
 """CPU: host logic of aggregate_neighbors.  Its arithmetic is this repo's own
-definition (parity unpinned, pigs_amd/aggregate.py); what the reference fixes -- shapes, float64,
+definition (parity unpinned; oracle/aggregate_torch.py is the dense torch checker of pigs_amd/csrc/aggregate.hip); what the reference fixes -- shapes, float64,
 differentiability wrt all six arguments (test_neighbor_aggregation.py:75-98) -- is checked here
 with the same torch.autograd.gradcheck call and the same sizes."""
 import math
 
 import torch
 
-from pigs_amd import aggregate
+from oracle import aggregate_torch as aggregate
 
 
 def setup(nx=5, d=2, L=2, K=4, E=21):

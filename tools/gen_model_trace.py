@@ -19,7 +19,7 @@ boundary points, ``randomize`` / ``set_initial_params``, ``sample``, then per ti
 ``compute_loss`` -> ``backward`` -> ``optim.step`` -> ``clear`` / ``sample`` / ``detach``); main_pn.py
 itself cannot be imported (it needs a missing ``model`` module and data files).
 ``preprocess_aggregate`` / ``aggregate_neighbors`` have no visible reference semantics (parity
-unpinned); the stand-in serves them with pigs_amd.aggregate on the CPU so that the model runs.
+unpinned); the stand-in serves them with the repo's dense torch checker (oracle/aggregate_torch.py) so that the model runs.
 
     python tools/gen_model_trace.py            # writes tests/golden/model_pn_trace_*.npz
 
@@ -136,11 +136,11 @@ class RecordingSampler:
 
     # parity unpinned: served by this repo's own definition so that the model runs
     def preprocess_aggregate(self):
-        from pigs_amd import aggregate
+        from oracle import aggregate_torch as aggregate
         self._agg = aggregate.neighbor_structure(self.m.detach(), self.c.detach(), 36.0)
 
     def aggregate_neighbors(self, features, transform, queries, keys, frequencies, distance_transform):
-        from pigs_amd import aggregate
+        from oracle import aggregate_torch as aggregate
         mask, delta, g = self._agg
         return aggregate.aggregate(mask, delta.to(features.dtype), g.to(features.dtype), features, transform, queries,
                                    keys, frequencies, distance_transform)
