@@ -25,6 +25,21 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)   # float32 cannot hold less
 
 
+def elementwise_ok(a, b, rtol=1e-5, floor=1e-6):
+    """Every element on its own: |a - b| <= rtol |b| + floor max|b|.  The global metric above never looks at
+    the small outputs; this one holds each of them to 1e-5 relative, with an absolute floor ten times
+    below the old bar (float32 sums that nearly cancel cannot do better than a few 1e-7 of the largest
+    output: tools/elem_err.py measured <= 7.5e-7 of the maximum, dense and binned alike)."""
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return bool((np.abs(a - b) <= rtol * np.abs(b) + floor * max(np.abs(b).max(), 1e-30)).all())
+
+
+def input_rounding(exp_rounded, ref):
+    """Distance between the float64 oracle on the float32-rounded inputs and the reference's float64 outputs
+    on the unrounded ones: what the rounding of the INPUTS costs, whatever the kernel does."""
+    return np.abs(np.asarray(exp_rounded) - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
 def dev(a, dtype):
     return torch.as_tensor(np.asarray(a), dtype=dtype, device="cuda")
 
@@ -69,8 +84,10 @@ def test_forward_f32_matches_reference(Sampler, name, fuse):
     for o, out in enumerate(outs):
         assert out.dtype == torch.float32
         assert rel(out, exp[o]) < F32_TOL, (name, o)
-        # ... and the reference's own float64 outputs on the unrounded inputs
-        assert rel(out, z[f"out{o}_f64"]) < 2 * F32_TOL, (name, o)
+        assert elementwise_ok(out, exp[o]), (name, o)
+        # ... and the reference's own float64 outputs on the unrounded inputs: the same bar plus exactly
+        # what rounding the inputs to float32 costs (measured on the oracle, not granted as a factor)
+        assert rel(out, z[f"out{o}_f64"]) < F32_TOL + input_rounding(exp[o], z[f"out{o}_f64"]), (name, o)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, F64_TOL), (torch.float32, F32_TOL)])
@@ -98,8 +115,8 @@ def test_backward_per_order_matches_reference_autograd(Sampler, name, dtype, tol
         assert rel(gv, ev) < tol, (name, o, "values")
         assert rel(gc, ec) < tol, (name, o, "conics")
         if dtype == torch.float32:
-            assert rel(gm, z[f"gmeans{o}_f64"]) < 3 * tol
-            assert rel(gc, z[f"gconics{o}_f64"]) < 3 * tol
+            assert rel(gm, z[f"gmeans{o}_f64"]) < tol + input_rounding(em, z[f"gmeans{o}_f64"])
+            assert rel(gc, z[f"gconics{o}_f64"]) < tol + input_rounding(ec, z[f"gconics{o}_f64"])
 
 
 @pytest.mark.parametrize("name", ["random_d2_c2.npz", "ref_test_derivatives.npz", "random_d1_c2.npz"])
@@ -130,8 +147,11 @@ def test_no_grad_and_sample_api(Sampler):
         s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
         u, ux, uxx, uxxx = s.sample((0, 1, 2, 3))
     assert not u.requires_grad
+    exp = c_oracle.forward(*(t[k].cpu().double().numpy() for k in ("means", "conics", "values", "samples")),
+                           orders=(0, 1, 2, 3))
     for o, out in enumerate((u, ux, uxx, uxxx)):
-        assert rel(out, z[f"out{o}_f64"]) < 2 * F32_TOL
+        assert rel(out, exp[o]) < F32_TOL
+        assert rel(out, z[f"out{o}_f64"]) < F32_TOL + input_rounding(exp[o], z[f"out{o}_f64"])
     # derivative outputs are symmetric in their derivative indices
     assert torch.equal(uxx[:, 0, 1], uxx[:, 1, 0])
     assert torch.equal(uxxx[:, 0, 0, 1], uxxx[:, 1, 0, 0])
@@ -145,7 +165,9 @@ def test_1d_call_shapes(Sampler):
     assert tuple(s.sample_gaussians().shape) == (200, 1)
     assert tuple(s.sample_gaussians_derivative().shape) == (200, 1, 1)
     assert tuple(s.sample_gaussians_laplacian().shape) == (200, 1, 1, 1)
-    assert rel(s.sample_gaussians_laplacian(), z["out2_f64"]) < 2 * F32_TOL
+    exp = c_oracle.forward(*(t[k].cpu().double().numpy() for k in ("means", "conics", "values", "samples")), orders=(2,))
+    assert rel(s.sample_gaussians_laplacian(), exp[2]) < F32_TOL
+    assert rel(s.sample_gaussians_laplacian(), z["out2_f64"]) < F32_TOL + input_rounding(exp[2], z["out2_f64"])
 
 
 def test_masked_noncontiguous_inputs(Sampler):
