@@ -30,6 +30,13 @@ def shard_rows(n_items, world_size=None, rank=None):
     return slice(*shard_bounds(n_items, world_size, rank))
 
 
+def _numel(shape):
+    n = 1
+    for k in shape:
+        n *= k
+    return n
+
+
 class _Replicated(torch.autograd.Function):
     """Identity on the replicated parameters; the backward sums their gradients over the ranks
     with a single all-reduce of one packed buffer."""
@@ -37,21 +44,28 @@ class _Replicated(torch.autograd.Function):
     @staticmethod
     def forward(ctx, group, *params):
         ctx.group = group
+        ctx.shapes = [tuple(p.shape) for p in params]
         return tuple(p.view_as(p) for p in params)
 
     @staticmethod
     def backward(ctx, *grads):
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1):
             return (None, *grads)          # single process: nothing to sum, no packing copy either
-        shapes = [g.shape for g in grads]
+        if all(g is None for g in grads):
+            return (None, *grads)
+        # one packed [N, d + d(d+1)/2 + c] buffer: whatever arrives (expanded, transposed, sliced views, or
+        # nothing at all for a parameter the loss did not touch) is laid out contiguously before the ONE
+        # collective; every rank packs the same layout, so the ranks may differ in which gradients exist
+        shapes = ctx.shapes
         n = shapes[0][0]
-        packed = torch.cat([g.reshape(n, -1) for g in grads], dim=1).contiguous()
+        ref = next(g for g in grads if g is not None)
+        cols = [g.reshape(n, -1) if g is not None else ref.new_zeros((n, max(1, _numel(shp) // max(n, 1))))
+                for g, shp in zip(grads, shapes)]
+        packed = torch.cat(cols, dim=1).contiguous()
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
         out, col = [], 0
         for shp in shapes:
-            w = 1
-            for k in shp[1:]:
-                w *= k
+            w = _numel(shp) // max(n, 1)
             out.append(packed[:, col:col + w].reshape(shp))
             col += w
         return (None, *out)

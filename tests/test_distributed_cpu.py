@@ -72,6 +72,52 @@ def test_sharded_forward_and_allreduced_grads(name):
         assert np.array_equal(results[0][idx], results[1][idx])
 
 
+def _worker_views(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pigs_amd import distributed as D
+        g = torch.Generator().manual_seed(7)
+        means = torch.randn((9, 2), generator=g, dtype=torch.float64).requires_grad_(True)
+        values = torch.randn((9, 2), generator=g, dtype=torch.float64).requires_grad_(True)
+        conics = torch.randn((9, 3), generator=g, dtype=torch.float64).requires_grad_(True)
+        w = torch.randn((3, 9), generator=g, dtype=torch.float64)
+        m_r, v_r, c_r = D.replicated(means, values, conics)
+        # gradients that reach the packing as non-contiguous views: an expanded scalar (stride 0) for the
+        # means, a transposed matrix for the conics; the values get none at all on rank 1
+        loss = (rank + 1) * m_r.sum() + (c_r.t() * w).sum() * (2 - rank)
+        if rank == 0:
+            loss = loss + (v_r[:, 1] ** 2).sum()
+        loss.backward()
+        out_q.put((rank, means.grad.numpy(), values.grad.numpy(), conics.grad.numpy(), values.detach().numpy(), w.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_allreduce_with_noncontiguous_and_missing_grads():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_views, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    values, w = results[0][4], results[0][5]
+    exp_means = np.full((9, 2), 1.0 + 2.0)
+    exp_values = np.zeros((9, 2))
+    exp_values[:, 1] = 2 * values[:, 1]
+    exp_conics = w.T * (2 + 1)
+    for r in results:
+        assert np.allclose(r[1], exp_means, rtol=0, atol=1e-14)
+        assert np.allclose(r[2], exp_values, rtol=0, atol=1e-14)
+        assert np.allclose(r[3], exp_conics, rtol=0, atol=1e-14)
+
+
 def test_shard_bounds_cover_everything():
     from pigs_amd.distributed import shard_bounds
     for n in (0, 1, 7, 1024, 1000003):
