@@ -26,7 +26,7 @@
 #define PIGS_FWD_UNROLL 2     // list rows evaluated per loop iteration
 #endif
 #ifndef PIGS_BWD_WAVES
-#define PIGS_BWD_WAVES 6      // waves per SIMD the register budget of the backward's narrow variants is held to
+#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to (its LDS allows 4 workgroups per CU)
 #endif
 #ifndef PIGS_TRAV_STEPS
 #define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
@@ -405,16 +405,30 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
 // edge(s) facing the centre; each facing edge is minimised in closed form.  Comparisons are
 // written so that NaN (degenerate conic) accepts.
 // ------------------------------------------------------------------------------------------
+struct Ellipse {
+    float x, y, a, b, c, nb_c, nb_a;      // centre, conic, -b/c, -b/a
+};
+// what depends on the Gaussian alone (two reciprocals), prepared once and reused for the tile's box
+// and its four group boxes
+__device__ __forceinline__ Ellipse ellipse_of(float4 A, float cc) {
+    Ellipse e;
+    e.x = A.x; e.y = A.y; e.a = A.z; e.b = A.w; e.c = cc;
+    e.nb_c = -A.w * __builtin_amdgcn_rcpf(cc);
+    e.nb_a = -A.w * __builtin_amdgcn_rcpf(A.z);
+    return e;
+}
+__device__ __forceinline__ bool ellipse_reaches_rect(const Ellipse& e, float x0, float y0, float x1, float y1, float q_max) {
+    const float l = x0 - e.x, r = x1 - e.x, bt = y0 - e.y, tp = y1 - e.y;
+    const float xe = clampf(0.f, l, r), ye = clampf(0.f, bt, tp);
+    const float ys = clampf(e.nb_c * xe, bt, tp);
+    const float xs = clampf(e.nb_a * ye, l, r);
+    const float q1 = e.a * xe * xe + (2.f * e.b * xe + e.c * ys) * ys;
+    const float q2 = e.c * ye * ye + (2.f * e.b * ye + e.a * xs) * xs;
+    return !(fminf(q1, q2) > q_max);
+}
 __device__ __forceinline__ bool ellipse_reaches_rect(float4 A, float cc, float x0, float y0, float x1, float y1,
                                                      float q_max) {
-    const float l = x0 - A.x, r = x1 - A.x, bt = y0 - A.y, tp = y1 - A.y;
-    const float a = A.z, b = A.w;
-    const float xe = clampf(0.f, l, r), ye = clampf(0.f, bt, tp);
-    const float ys = clampf(-b * xe * __builtin_amdgcn_rcpf(cc), bt, tp);
-    const float xs = clampf(-b * ye * __builtin_amdgcn_rcpf(a), l, r);
-    const float q1 = a * xe * xe + (2.f * b * xe + cc * ys) * ys;
-    const float q2 = cc * ye * ye + (2.f * b * ye + a * xs) * xs;
-    return !(fminf(q1, q2) > q_max);
+    return ellipse_reaches_rect(ellipse_of(A, cc), x0, y0, x1, y1, q_max);
 }
 
 // Workgroups are dispatched round-robin over the 8 XCDs (workgroup i runs on XCD i % 8) and every
@@ -649,11 +663,16 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds, true,
              [](int, uint32_t, uint32_t) {},
              [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
+#if defined(PIGS_LISTS_DEBUG)
+        n += (uint32_t)__builtin_popcountll(mask);      // timing probe: traversal only, no group tests, no lists
+        return;
+#endif
         uint32_t gm = 0;
+        const Ellipse e = ellipse_of(A, B.x);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // a group without a point (the ragged last tile) has an inverted box: never needed
-            if (gx0[g] <= gx1[g] && ellipse_reaches_rect(A, B.x, gx0[g], gy0[g], gx1[g], gy1[g], pv.q_max)) gm |= 1u << g;
+            if (gx0[g] <= gx1[g] && ellipse_reaches_rect(e, gx0[g], gy0[g], gx1[g], gy1[g], pv.q_max)) gm |= 1u << g;
         }
         if (!(mask >> lane & 1ull)) gm = 0u;
         const uint64_t km = __ballot(gm != 0u);
@@ -948,7 +967,8 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
 // all-zero record to the longest of the four.
 // ------------------------------------------------------------------------------------------
 #ifndef PIGS_BWD_STEP
-#define PIGS_BWD_STEP 32      // entries per step of the backward: its LDS (records, lists, sums table) scales with it
+#define PIGS_BWD_STEP 64      // entries per step of the backward: its LDS (records, lists, sums table) scales with it
+                              // (32 doubles the resident waves and splits C3's 49-entry lists in two steps: 83 vs 81 us)
 #endif
 constexpr int BWD_STEP = PIGS_BWD_STEP;
 static_assert(BWD_STEP == 32 || BWD_STEP == 64, "entries per step");

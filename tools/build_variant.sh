@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/variants
 hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize -Wno-unused-function "$@" \
-  -o build/variants/libpigs_$name.so pigs_amd/csrc/capi.hip pigs_amd/csrc/covariances.hip pigs_amd/csrc/dense.hip pigs_amd/csrc/plan.hip
+  -o build/variants/libpigs_$name.so pigs_amd/csrc/*.hip
 echo build/variants/libpigs_$name.so
