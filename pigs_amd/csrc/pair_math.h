@@ -28,7 +28,13 @@ template <int D> struct Sym {
 template <typename T> __device__ __forceinline__ T exp_neg_half(T q);
 template <> __device__ __forceinline__ float exp_neg_half<float>(float q) {
     // v_exp_f32 on a pre-scaled argument: exp(-q/2) = 2^(-q * log2(e)/2)
+#ifdef PIGS_EXP_SCALE_VGPR
+    float k;          // the factor from a register instead of a 32-bit literal (no "volatile": hoisted out of loops)
+    asm("v_mov_b32 %0, 0xbf38aa3b" : "=v"(k));
+    return __builtin_amdgcn_exp2f(q * k);
+#else
     return __builtin_amdgcn_exp2f(q * -0.72134752044448170368f);
+#endif
 }
 template <> __device__ __forceinline__ double exp_neg_half<double>(double q) { return exp(-0.5 * q); }
 

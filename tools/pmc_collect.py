@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 PMC passes of `bench.py` into profiles/pmc_traffic.json.
+"""Fold rocprofv3 PMC passes of the forward launch into profiles/pmc_traffic.json.
 
 On the GPU box (each counter set in its own run, kernel trace only -- never with sys/hip traces):
-    cd /tmp && export TMPDIR=/tmp
-    for set in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
-               "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
-        rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_<n> -o pmc -- \
-            python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-bwd
-    done
-then here:  python tools/pmc_collect.py gpurun_out/pmc_*  [--key c3:kappa=0.5:binned]
+    tools/pmc_run.sh fetch  "FETCH_SIZE"               fwd --steps 20 [--kappa K]
+    tools/pmc_run.sh write  "WRITE_SIZE"               fwd --steps 20 [--kappa K]
+    tools/pmc_run.sh hit    "TCC_HIT_sum TCC_MISS_sum" fwd --steps 20 [--kappa K]
+    tools/pmc_run.sh sq     "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" fwd --steps 20
+then here:  python tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write ... [--key c3:kappa=0.5:binned]
 Units: FETCH_SIZE / WRITE_SIZE are KiB (MI355X_MICROARCH.md "HBM"); on gfx950 FETCH_SIZE counts wide
 reads at half their size, so the corrected figure is (2 x FETCH_SIZE + WRITE_SIZE) KiB.
+The record carries the hash of the kernel sources it was measured on (pigs_amd.build.source_hash):
+bench.py reports the traffic only while that hash still matches.
 """
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, importlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 key = "c3:kappa=0.5:binned"
 if "--key" in sys.argv:
@@ -28,28 +29,29 @@ for d in args:
             per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"], r["Counter_Name"])] += float(r["Counter_Value"])
         for (_, k, c), v in per_dispatch.items():
             if "pigs::" in k:
-                acc[k.split("(")[0]][c].append(v)
+                acc[k.split("(")[0].replace("void ", "")][c].append(v)
 allk = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
-fw = next((v for k, v in allk.items() if "binned_forward_kernel" in k), None)
+fw = next((v for k, v in allk.items() if "tile_forward_kernel<1, 7>" in k), None)
 if fw is None or "FETCH_SIZE" not in fw or "WRITE_SIZE" not in fw:
     raise SystemExit("no forward-kernel FETCH_SIZE / WRITE_SIZE found in " + " ".join(args))
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 table = json.load(open(path)) if os.path.exists(path) else {}
 N, M = 65536, 1 << 20
 table[key] = {
-    "kernel": "binned_forward_kernel<1,7>",
+    "kernel": "tile_forward_kernel<1,7>",
+    "source_hash": importlib.import_module("pigs_amd.build").source_hash(),
     "FETCH_SIZE_KiB": fw["FETCH_SIZE"], "WRITE_SIZE_KiB": fw["WRITE_SIZE"],
     "hbm_bytes_raw": (fw["FETCH_SIZE"] + fw["WRITE_SIZE"]) * 1024,
     "hbm_bytes_per_launch": (2 * fw["FETCH_SIZE"] + fw["WRITE_SIZE"]) * 1024,
     "algorithmic_bytes": 24 * N + 36 * M,
     "TCC_HIT_sum": fw.get("TCC_HIT_sum"), "TCC_MISS_sum": fw.get("TCC_MISS_sum"),
     "SQ": {c: v for c, v in fw.items() if c.startswith("SQ_")},
-    "how": "tools/pmc_collect.py over separate rocprofv3 --kernel-trace --pmc passes of `bench.py --steps 5 --warmup 1 "
-           "--no-cpu-baseline --no-bwd` (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum+TCC_MISS_sum; the SQ set); mean over the "
-           "launches of the kernel. Units KiB (MI355X_MICROARCH.md 'HBM'). gfx950 FETCH_SIZE halves wide reads: "
+    "how": "tools/pmc_collect.py over separate rocprofv3 --kernel-trace --pmc passes of `tools/prof_step.py fwd --steps 20` "
+           "(the forward launch alone on one plan; FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum+TCC_MISS_sum; the SQ set); mean over "
+           "the launches of the kernel. Units KiB (MI355X_MICROARCH.md 'HBM'). gfx950 FETCH_SIZE halves wide reads: "
            "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB is the corrected upper figure, hbm_bytes_raw the "
            "uncorrected one.",
 }
-table["all_kernels"] = allk      # other keys of the table (e.g. fetch_size_calibration) are kept
+table["all_kernels"] = {**table.get("all_kernels", {}), **allk}
 json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(table[key], indent=1))
