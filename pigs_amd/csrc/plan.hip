@@ -418,10 +418,12 @@ __device__ __forceinline__ Ellipse ellipse_of(float4 A, float cc) {
     return e;
 }
 __device__ __forceinline__ bool ellipse_reaches_rect(const Ellipse& e, float x0, float y0, float x1, float y1, float q_max) {
+    // clamp(v, lo, hi) with lo <= hi is the median of the three (one v_med3_f32; like the min / max
+    // pair it returns a bound when v is NaN)
     const float l = x0 - e.x, r = x1 - e.x, bt = y0 - e.y, tp = y1 - e.y;
-    const float xe = clampf(0.f, l, r), ye = clampf(0.f, bt, tp);
-    const float ys = clampf(e.nb_c * xe, bt, tp);
-    const float xs = clampf(e.nb_a * ye, l, r);
+    const float xe = __builtin_amdgcn_fmed3f(0.f, l, r), ye = __builtin_amdgcn_fmed3f(0.f, bt, tp);
+    const float ys = __builtin_amdgcn_fmed3f(e.nb_c * xe, bt, tp);
+    const float xs = __builtin_amdgcn_fmed3f(e.nb_a * ye, l, r);
     const float q1 = e.a * xe * xe + (2.f * e.b * xe + e.c * ys) * ys;
     const float q2 = e.c * ye * ye + (2.f * e.b * ye + e.a * xs) * xs;
     return !(fminf(q1, q2) > q_max);
@@ -493,12 +495,12 @@ __device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, flo
 //      (ellipse against box) and handed to `batch(A, B, mask, j)`: this lane's record and its
 //      sorted Gaussian index, `mask` = the lanes that hold an accepted one.
 // ------------------------------------------------------------------------------------------
-constexpr int CCAP = 256;   // bbox-accepted candidate indices buffered per wave before the exact test
-static_assert(CCAP >= 128, "a batch of two steps adds up to 128 candidates behind a flush");
+constexpr int CCAP = 128 * PIGS_TRAV_STEPS;   // bbox-accepted candidate indices buffered per wave before the exact test
+static_assert(CCAP >= 128 * PIGS_TRAV_STEPS, "room for one more batch of steps below the flush threshold");
 struct TravLds {
     uint32_t row_a0[64];
     uint32_t row_a1[64];
-    uint32_t cand[CCAP + 64];
+    uint32_t cand[CCAP];
 };
 
 template <typename Rows, typename Batch>
@@ -546,7 +548,7 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
         if (!walk) continue;
         int r = -1;
         uint32_t j0 = 0, je = 0;
-        auto advance = [&]() -> bool {
+        auto advance = [&]() __attribute__((always_inline)) -> bool {
             j0 += 64;
             while (j0 >= je) {
                 if (++r >= nrow) return false;
@@ -556,69 +558,85 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
             return true;
         };
         int cn = 0;
-        auto exact_stage = [&]() {
+        auto exact_stage = [&]() __attribute__((always_inline)) {
             wave_lds_fence();
-            for (int b0 = 0; b0 < cn; b0 += 128) {
-                // two gathers in flight
-                const bool in0 = b0 + lane < cn, in1 = b0 + 64 + lane < cn;
-                const uint32_t i0 = in0 ? lds.cand[b0 + lane] : lds.cand[0];
-                const uint32_t i1 = in1 ? lds.cand[b0 + 64 + lane] : lds.cand[0];
-                const float4 A0 = pv.rec[2 * i0], B0 = pv.rec[2 * i0 + 1];
-                float4 A1 = A0, B1 = B0;
-                if (b0 + 64 < cn) { A1 = pv.rec[2 * i1]; B1 = pv.rec[2 * i1 + 1]; }
-                const uint64_t m0 = __ballot(in0 && ellipse_reaches_rect(A0, B0.x, bx0, by0, bx1, by1, pv.q_max));
-                if (m0) batch(A0, B0, m0, i0);
+            // the next step's records are requested before the current step is tested and handed on
+            uint32_t i = lane < cn ? lds.cand[lane] : lds.cand[0];
+            float4 A = pv.rec[2 * i], B = pv.rec[2 * i + 1];
+            for (int b0 = 0; b0 < cn; b0 += 64) {
+                const bool in = b0 + lane < cn;
+                const uint32_t ic = i;
+                const float4 Ac = A, Bc = B;
                 if (b0 + 64 < cn) {
-                    const uint64_t m1 = __ballot(in1 && ellipse_reaches_rect(A1, B1.x, bx0, by0, bx1, by1, pv.q_max));
-                    if (m1) batch(A1, B1, m1, i1);
+                    i = b0 + 64 + lane < cn ? lds.cand[b0 + 64 + lane] : lds.cand[0];
+                    A = pv.rec[2 * i]; B = pv.rec[2 * i + 1];
                 }
+                const uint64_t m = __ballot(in && ellipse_reaches_rect(Ac, Bc.x, bx0, by0, bx1, by1, pv.q_max));
+                if (m) batch(Ac, Bc, m, ic);
             }
             wave_lds_fence();
             cn = 0;
         };
         bool have = advance();
-        while (have) {
-            uint32_t sj[PIGS_TRAV_STEPS], se[PIGS_TRAV_STEPS];
-            float4 T[PIGS_TRAV_STEPS];
-            int ns = 0;
+        while (have || cn > 0) {
+            if (have) {
+                uint32_t sj[PIGS_TRAV_STEPS], se[PIGS_TRAV_STEPS];
+                float4 T[PIGS_TRAV_STEPS];
+                int ns = 0;
 #pragma unroll
-            for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
-                sj[u] = j0; se[u] = je;
-                if (have) {
-                    ns = u + 1;
-                    const uint32_t j = j0 + lane < je ? j0 + lane : j0;
-                    T[u] = pv.gbox[j];
-                    have = advance();
-                } else {
-                    se[u] = sj[u];          // empty step
-                    T[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
+                    sj[u] = j0; se[u] = je;
+                    if (have) {
+                        ns = u + 1;
+                        const uint32_t j = j0 + lane < je ? j0 + lane : j0;
+                        T[u] = pv.gbox[j];
+                        have = advance();
+                    } else {
+                        se[u] = sj[u];          // empty step
+                        T[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
-                if (u < ns) {
-                    const float ex = fmaxf(fmaxf(bx0 - T[u].x, T[u].x - bx1), 0.f);
-                    const float ey = fmaxf(fmaxf(by0 - T[u].y, T[u].y - by1), 0.f);
-                    const bool ok = (sj[u] + lane < se[u]) && ex <= T[u].z && ey <= T[u].w;
-                    const uint64_t mask = __ballot(ok);
-                    if (mask) {
-                        if (ok) lds.cand[cn + lanes_below(mask)] = sj[u] + lane;
-                        cn += __builtin_popcountll(mask);
-                        if (cn > CCAP - 64) exact_stage();
+                for (int u = 0; u < PIGS_TRAV_STEPS; ++u) {
+                    if (u < ns) {
+                        const float ex = fmaxf(fmaxf(bx0 - T[u].x, T[u].x - bx1), 0.f);
+                        const float ey = fmaxf(fmaxf(by0 - T[u].y, T[u].y - by1), 0.f);
+                        const bool ok = (sj[u] + lane < se[u]) && ex <= T[u].z && ey <= T[u].w;
+                        const uint64_t mask = __ballot(ok);
+                        if (mask) {
+                            if (ok) lds.cand[cn + lanes_below(mask)] = sj[u] + lane;
+                            cn += __builtin_popcountll(mask);
+                        }
                     }
                 }
             }
+            // one call site (the exact stage and everything the caller does per batch is inlined here once)
+            if (cn > CCAP - 64 * PIGS_TRAV_STEPS || !have) exact_stage();
         }
-        exact_stage();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Launch 5 of a plan build: the tile lists.  One wave = one tile: the boxes of its four 16-point
-// groups (DPP row reductions) and of the tile, one traversal against the tile's box, and for
-// every accepted Gaussian the four group tests; entries with an empty mask (the ellipse reaches
-// the tile's box but none of its groups') are dropped.
+// Launch 5 of a plan build: the tile lists.  One wave = LISTS_TPW consecutive tiles (4 tiles = 256
+// consecutive sorted points = one 4 x 4 block of sample cells): ONE traversal of the Gaussian grid
+// against the box of all of them -- the traversal is a chain of dependent loads and most of the
+// kernel's instructions, so it is shared -- whose survivors (exact ellipse-vs-box test) wait in
+// LDS with what the ellipse test needs of them; every 128 survivors, and at the end, each tile's
+// four 16-point groups are tested against them and the accepted ones appended to the tile's list
+// and group lists; entries with an empty mask are dropped.
 // ------------------------------------------------------------------------------------------
+#ifndef PIGS_LISTS_TPW
+#define PIGS_LISTS_TPW 4
+#endif
+constexpr int LISTS_TPW = PIGS_LISTS_TPW;
+constexpr int SURV_CAP = 128;
+struct ListsLds {
+    TravLds trav;
+    float4 sa[SURV_CAP];              // survivor: {mux, muy, a, b}
+    float4 sb[SURV_CAP];              //           {c, -b/c, -b/a, sorted index (bits)}
+    float4 gbox[LISTS_TPW * 4];       // boxes of the groups: {x0, y0, x1, y1}
+    uint32_t sel[SURV_CAP];           // positions of the survivors that reach the tile in hand
+};
 struct ListArgs {
     PlanView pv;
     SamplesView sv;
@@ -628,87 +646,147 @@ struct ListArgs {
 };
 
 __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
-    __shared__ TravLds lds_all[4];
+    __shared__ ListsLds lds_all[4];
     const PlanView& pv = a.pv;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
-    if (tile >= a.sv.ntiles) return;
-    TravLds& lds = lds_all[wave];
+    const uint32_t tile0 = (xcd_block() * 4 + (uint32_t)wave) * LISTS_TPW;
+    const uint32_t ntiles = a.sv.ntiles;
+    if (tile0 >= ntiles) return;
+    ListsLds& lds = lds_all[wave];
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
     const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
     const float INF = __builtin_huge_valf();
-    const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
-    const bool valid = m < a.sv.M;
-    SPoint sp = {0.f, 0.f, 0u};
-    if (valid) sp = a.sv.spts[m];
-    float x0 = valid ? sp.x : INF, x1 = valid ? sp.x : -INF, y0 = valid ? sp.y : INF, y1 = valid ? sp.y : -INF;
-    row_box_dpp(x0, x1, y0, y1);
-    float gx0[4], gx1[4], gy0[4], gy1[4];
+    SPoint sp[LISTS_TPW];
+    bool valid[LISTS_TPW];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        gx0[g] = readlane_f(x0, 16 * g); gx1[g] = readlane_f(x1, 16 * g);
-        gy0[g] = readlane_f(y0, 16 * g); gy1[g] = readlane_f(y1, 16 * g);
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        const uint32_t m = (tile0 + (uint32_t)t) * TILE_POINTS + (uint32_t)lane;
+        valid[t] = m < a.sv.M;           // also false for every point of a tile behind the last one
+        sp[t] = SPoint{0.f, 0.f, 0u};
+        if (valid[t]) sp[t] = a.sv.spts[m];
     }
-    wave_box_from_rows_dpp(x0, x1, y0, y1);
-    const float bx0 = x0, bx1 = x1, by0 = y0, by1 = y1;
+    float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
+#pragma unroll
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        float x0 = valid[t] ? sp[t].x : INF, x1 = valid[t] ? sp[t].x : -INF;
+        float y0 = valid[t] ? sp[t].y : INF, y1 = valid[t] ? sp[t].y : -INF;
+        row_box_dpp(x0, x1, y0, y1);
+        if ((lane & 15) == 0) lds.gbox[t * 4 + (lane >> 4)] = make_float4(x0, y0, x1, y1);
+        bx0 = fminf(bx0, x0); bx1 = fmaxf(bx1, x1); by0 = fminf(by0, y0); by1 = fmaxf(by1, y1);
+    }
+    wave_box_from_rows_dpp(bx0, bx1, by0, by1);
 
     const uint32_t cap = pv.list_cap;
-    uint32_t* tl = a.tlist + (size_t)tile * cap;
-    uint32_t* gl = a.glist + (size_t)tile * 4 * cap;
-    uint32_t* hd = a.hdr + (size_t)tile * TILE_HDR_WORDS;
-    uint32_t n = 0, ng[4] = {0, 0, 0, 0};
-    bool overflow = false;
-    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds, true,
-             [](int, uint32_t, uint32_t) {},
-             [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) {
-#if defined(PIGS_LISTS_DEBUG)
-        n += (uint32_t)__builtin_popcountll(mask);      // timing probe: traversal only, no group tests, no lists
-        return;
-#endif
-        uint32_t gm = 0;
-        const Ellipse e = ellipse_of(A, B.x);
+    uint32_t n[LISTS_TPW], ng[LISTS_TPW][4];
+    bool overflow[LISTS_TPW];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // a group without a point (the ragged last tile) has an inverted box: never needed
-            if (gx0[g] <= gx1[g] && ellipse_reaches_rect(e, gx0[g], gy0[g], gx1[g], gy1[g], pv.q_max)) gm |= 1u << g;
-        }
-        if (!(mask >> lane & 1ull)) gm = 0u;
-        const uint64_t km = __ballot(gm != 0u);
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
-        if (n + cnt <= cap) {
-            if (gm != 0u) tl[n + (uint32_t)lanes_below(km)] = j | (gm << LIST_IDX_BITS);
-        } else {
-            overflow = true;
-        }
-        n += cnt;
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        n[t] = 0; overflow[t] = false;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint64_t mg = __ballot(gm >> g & 1u);
-            const uint32_t cg = (uint32_t)__builtin_popcountll(mg);
-            if (ng[g] + cg <= cap) {
-                if (gm >> g & 1u) gl[g * cap + ng[g] + (uint32_t)lanes_below(mg)] = j;
+        for (int g = 0; g < 4; ++g) ng[t][g] = 0;
+    }
+    int sn = 0;
+    // the tiles' tests on the survivors in LDS: per tile, (A) the survivors that reach the tile's
+    // box, compacted (their positions, one byte each would do: 128 survivors), then (B) the four
+    // group tests on those: usually one step of 64 instead of two
+    auto flush = [&]() __attribute__((always_inline)) {
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < LISTS_TPW; ++t) {
+            if (tile0 + (uint32_t)t >= ntiles) continue;
+            float4 gb[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gb[g] = lds.gbox[t * 4 + g];
+            const float tx0 = fminf(fminf(gb[0].x, gb[1].x), fminf(gb[2].x, gb[3].x));
+            const float ty0 = fminf(fminf(gb[0].y, gb[1].y), fminf(gb[2].y, gb[3].y));
+            const float tx1 = fmaxf(fmaxf(gb[0].z, gb[1].z), fmaxf(gb[2].z, gb[3].z));
+            const float ty1 = fmaxf(fmaxf(gb[0].w, gb[1].w), fmaxf(gb[2].w, gb[3].w));
+            int sel = 0;
+            for (int s0 = 0; s0 < sn; s0 += 64) {
+                const int k = s0 + lane < sn ? s0 + lane : 0;
+                const float4 A = lds.sa[k], B = lds.sb[k];
+                Ellipse e;
+                e.x = A.x; e.y = A.y; e.a = A.z; e.b = A.w; e.c = B.x; e.nb_c = B.y; e.nb_a = B.z;
+                const bool hit = s0 + lane < sn && ellipse_reaches_rect(e, tx0, ty0, tx1, ty1, pv.q_max);
+                const uint64_t hm = __ballot(hit);
+                if (hit) lds.sel[sel + lanes_below(hm)] = (uint32_t)k;
+                sel += __builtin_popcountll(hm);
             }
-            ng[g] += cg;        // a group list is never longer than the tile list: overflow is caught above
+            wave_lds_fence();
+            uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+            uint32_t* gl = a.glist + (size_t)(tile0 + (uint32_t)t) * 4 * cap;
+            for (int s0 = 0; s0 < sel; s0 += 64) {
+                const int k = (int)lds.sel[s0 + lane < sel ? s0 + lane : 0];
+                const float4 A = lds.sa[k], B = lds.sb[k];
+                Ellipse e;
+                e.x = A.x; e.y = A.y; e.a = A.z; e.b = A.w; e.c = B.x; e.nb_c = B.y; e.nb_a = B.z;
+                const uint32_t j = __builtin_bit_cast(uint32_t, B.w);
+                uint32_t gm = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // a group without a point (the ragged last tile) has an inverted box: never needed
+                    const bool hit = ellipse_reaches_rect(e, gb[g].x, gb[g].y, gb[g].z, gb[g].w, pv.q_max);
+                    if (hit && gb[g].x <= gb[g].z) gm |= 1u << g;
+                }
+                if (s0 + lane >= sel) gm = 0u;
+                const uint64_t km = __ballot(gm != 0u);
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
+                if (n[t] + cnt <= cap) {
+                    if (gm != 0u) tl[n[t] + (uint32_t)lanes_below(km)] = j | (gm << LIST_IDX_BITS);
+                } else {
+                    overflow[t] = true;
+                }
+                n[t] += cnt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint64_t mg = __ballot(gm >> g & 1u);
+                    const uint32_t cg = (uint32_t)__builtin_popcountll(mg);
+                    if (ng[t][g] + cg <= cap) {
+                        if (gm >> g & 1u) gl[g * cap + ng[t][g] + (uint32_t)lanes_below(mg)] = j;
+                    }
+                    ng[t][g] += cg;     // a group list is never longer than the tile list: overflow is caught above
+                }
+            }
+            wave_lds_fence();
         }
+        sn = 0;
+    };
+    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.trav, true,
+             [](int, uint32_t, uint32_t) {},
+             [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) __attribute__((always_inline)) {
+        if (mask >> lane & 1ull) {
+            const Ellipse e = ellipse_of(A, B.x);
+            const int k = sn + lanes_below(mask);
+            lds.sa[k] = A;
+            lds.sb[k] = make_float4(B.x, e.nb_c, e.nb_a, __builtin_bit_cast(float, j));
+        }
+        sn += __builtin_popcountll(mask);
+        if (sn > SURV_CAP - 64) flush();
     });
-    if (!overflow) {
-        if (lane < TILE_HDR_WORDS) {
+    if (sn > 0) flush();
+
+    bool any_overflow = false;
+#pragma unroll
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        if (tile0 + (uint32_t)t >= ntiles) continue;
+        any_overflow |= overflow[t];
+        if (!overflow[t] && lane < TILE_HDR_WORDS) {
             uint32_t w = 0;
-            if (lane == 0) w = n | (TILE_MODE_LIST << TILE_MODE_SHIFT);
+            if (lane == 0) w = n[t] | (TILE_MODE_LIST << TILE_MODE_SHIFT);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (lane == 1 + g) w = ng[g];
-            hd[lane] = w;
+                if (lane == 1 + g) w = ng[t][g];
+            a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = w;
         }
-        return;
     }
-    // The list does not fit: keep the grid's record ranges around the tile instead (pairs {first,
-    // length}); when even those do not fit, the single range of all Gaussians.
+    if (!any_overflow) return;
+    // A list does not fit: that tile keeps the grid's record ranges around the wave's tiles instead
+    // (pairs {first, length}); when even those do not fit, the single range of all Gaussians.
     uint32_t nr = 0;
     bool fits = true;
-    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds, false,
+    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.trav, false,
              [&](int nrow, uint32_t jb, uint32_t len) {
         const bool keep = lane < nrow && len > 0;
         const uint64_t km = __ballot(keep);
@@ -716,7 +794,12 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         if (2 * (nr + cnt) <= cap) {
             if (keep) {
                 const uint32_t p = 2 * (nr + (uint32_t)lanes_below(km));
-                tl[p] = jb; tl[p + 1] = len;
+#pragma unroll
+                for (int t = 0; t < LISTS_TPW; ++t) {
+                    if (!overflow[t]) continue;
+                    uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+                    tl[p] = jb; tl[p + 1] = len;
+                }
             }
         } else {
             fits = false;
@@ -724,11 +807,15 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         nr += cnt;
     },
              [](const float4, const float4, uint64_t, uint32_t) {});
-    if (!fits) {
-        if (lane == 0) { tl[0] = 0; tl[1] = pv.N; }
-        nr = 1;
+#pragma unroll
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        if (!overflow[t]) continue;
+        uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+        if (!fits && lane == 0) { tl[0] = 0; tl[1] = pv.N; }
+        const uint32_t cnt = fits ? nr : 1u;
+        if (lane < TILE_HDR_WORDS)
+            a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (cnt | (TILE_MODE_RANGES << TILE_MODE_SHIFT)) : 0u;
     }
-    if (lane < TILE_HDR_WORDS) hd[lane] = lane == 0 ? (nr | (TILE_MODE_RANGES << TILE_MODE_SHIFT)) : 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1342,7 +1429,7 @@ static int run_build(bool do_samples, bool do_plan, void* sws, size_t sws_bytes,
         la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
         la.tlist = (uint32_t*)((char*)ws + p.off_tlist);
         la.glist = (uint32_t*)((char*)ws + p.off_glist);
-        hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 3) / 4), dim3(256), 0, stream, la);
+        hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)), dim3(256), 0, stream, la);
     }
     return launch_status();
 }
