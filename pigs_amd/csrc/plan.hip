@@ -1198,6 +1198,29 @@ __device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 
     }
 }
 
+// Tiles that run at the same time should not be neighbours in the domain: neighbouring tiles share
+// most of their Gaussians, their waves start together and move in step, and their atomics then meet
+// on the same cache lines at the same moment (same-line atomics retire one every ~10 ns; measured
+// 82 -> 67 us at C3).  A multiplicative shuffle by a prime that does not divide the tile count
+// (one of five whose product exceeds any tile count) is a bijection on [0, ntiles).
+#ifndef PIGS_BWD_SPREAD
+#define PIGS_BWD_SPREAD 2     // 0 = tiles in launch order, 1 = shuffled over the whole domain (66.9 us),
+                              // 2 = inside the XCD chunks of 1024 tiles (65.5 us; the lines stay in one L2)
+#endif
+__device__ __forceinline__ uint32_t spread_tile(uint32_t t, uint32_t ntiles) {
+    if (t >= ntiles) return t;           // the launch's padding: stays outside
+#if PIGS_BWD_SPREAD == 1
+    const uint32_t p = ntiles % 37u ? 37u : ntiles % 41u ? 41u : ntiles % 43u ? 43u : ntiles % 47u ? 47u : 53u;
+    return (uint32_t)(((uint64_t)t * p) % ntiles);
+#elif PIGS_BWD_SPREAD == 2
+    const uint32_t base = t & ~1023u;
+    if (base + 1024u > ntiles) return t;
+    return base + ((t & 1023u) * 37u & 1023u);
+#else
+    return t;
+#endif
+}
+
 template <int C, int MASK>
 constexpr int bwd_waves() {      // the widest gradient sets get 3 waves (168 VGPRs): no spills
     return ((C == 2 && (MASK == 7 || MASK == 8 || MASK == 15)) || (C == 1 && MASK == 15)) ? 3
@@ -1213,7 +1236,7 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     __shared__ TileLdsBwd<NV> lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
+    const uint32_t tile = spread_tile(xcd_block() * 4 + (uint32_t)wave, sv.ntiles);
     if (tile >= sv.ntiles) return;
     TileLdsBwd<NV>& lds = lds_all[wave];
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
