@@ -373,11 +373,12 @@ def main():
             loss = ((u - lap) ** 2).mean() + (ux ** 2).mean()
             return torch.autograd.grad(loss, list(req.values()))
 
-        nb = max(1, min(a.steps, 20))
-        sampler_only_s = timed_steps(sampler_step, 2, nb) / nb
-        fwd_bwd = {"ms_per_step": timed_steps(train_step, 2, nb) / nb * 1e3,
+        nb = max(1, min(a.steps, 100))
+        wb = min(10, nb)        # eager steps settle after a few iterations (caching allocator, autograd graph reuse)
+        sampler_only_s = timed_steps(sampler_step, wb, nb) / nb
+        fwd_bwd = {"ms_per_step": timed_steps(train_step, wb, nb) / nb * 1e3,
                    "sampler_only_ms_per_step": sampler_only_s * 1e3,
-                   "trace_residual_ms_per_step": timed_steps(trace_step, 2, nb) / nb * 1e3, "steps": nb,
+                   "trace_residual_ms_per_step": timed_steps(trace_step, wb, nb) / nb * 1e3, "steps": nb,
                    "value": M * world / sampler_only_s,
                    "dist_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
                    "what": "value: points/s of the sampler-only step = preprocess (samples half reused) + fused fwd(0..2) "
