@@ -259,11 +259,13 @@ class GaussianSampler:
     40); ``"auto"`` picks
     binned for float32, d = 2, c <= 2 once N*M >= 2**26 pairs, where the plan pays for itself.
 
-    ``reuse_samples`` (extension, keyword only; binned path): when ``preprocess`` is called again with the
-    very same samples tensor (same storage, shape and version counter, i.e. not written to in
-    between) the sorted sample structure of the previous call is reused and only the Gaussian half
+    ``reuse_samples`` (extension, keyword only; binned path): when ``preprocess`` is called again with a
+    samples tensor it has seen recently (same storage, shape and version counter, i.e. not written
+    to in between) the sorted sample structure built for it is reused and only the Gaussian half
     of the plan is rebuilt -- the reference's roll-out binds new Gaussians to a fixed grid every
-    step (main_pn.py:317-324).  ``False`` rebuilds everything every time.
+    step (main_pn.py:317-324), its training step alternates between the collocation points and
+    the boundary points (model_pn.py:766-785).  ``True`` remembers the last 4 sample tensors, an
+    integer that many, ``False`` rebuilds everything every time.
 
     ``unpinned_aggregate`` (extension, keyword only): ``preprocess_aggregate`` / ``aggregate_neighbors``
     follow this repository's own definition (the reference's is not visible: parity unpinned) and
@@ -297,12 +299,13 @@ class GaussianSampler:
         self.q_max_order3 = float(q_max_order3) if q_max_order3 is not None else self.q_max + 8.0
         if self.q_max_order3 < self.q_max:
             raise ValueError("q_max_order3 must not be below q_max")
-        self.reuse_samples = bool(reuse_samples)
+        self.reuse_samples = 4 if reuse_samples is True else max(0, int(reuse_samples))
         self.unpinned_aggregate = bool(unpinned_aggregate)
         self._plan3 = None
         self._inputs = None
         self._plan = None
         self._sample_plan = None
+        self._sample_plans = []          # most recently used first, at most ``reuse_samples``
         self._samples_source = None
         self._cache = {}
         _lib.load()  # fail at construction, not at first use, if the HIP library is missing
@@ -373,16 +376,17 @@ class GaussianSampler:
         elif self.backend == "binned" and N > 0 and sc.shape[0] > 0:
             raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 2")
 
-    def _build_plan(self, q_max):
-        """A plan for the bound inputs; the samples half is reused when ``preprocess`` was handed the
-        same unmodified samples tensor as last time (``reuse_samples``)."""
+    def _build_plan(self, q_max, sample_plan=None):
+        """A plan for the bound inputs; the samples half is reused when ``preprocess`` was handed an
+        unmodified samples tensor it remembers (``reuse_samples``)."""
         mc, vc, cc, sc = self._inputs
-        sp = self._sample_plan
-        if sp is not None and not (self.reuse_samples and sp.matches(self._samples_source)):
-            sp = None
+        sp = sample_plan or next((p for p in self._sample_plans if p.matches(self._samples_source)), None)
         with torch.no_grad():
             plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source)
         self._sample_plan = plan.samples
+        if self.reuse_samples:
+            self._sample_plans = [plan.samples] + [p for p in self._sample_plans if p is not plan.samples]
+            del self._sample_plans[self.reuse_samples:]
         if self.debug:
             torch.cuda.synchronize(mc.device)
             plan.check()
@@ -399,7 +403,7 @@ class GaussianSampler:
         if self._plan is None or not mask & 8 or self.q_max_order3 == self.q_max:
             return self._plan
         if self._plan3 is None:
-            self._plan3 = self._build_plan(self.q_max_order3)
+            self._plan3 = self._build_plan(self.q_max_order3, self._plan.samples)     # same points: the sorted samples are shared
         return self._plan3
 
     def _compute(self, mask):

@@ -403,3 +403,42 @@ def test_crowded_cell_many_flushes(Sampler, c, orders):
     gH[:, 1, 1, :] = r
     em, ec, ev = c_oracle.backward(*args, {2: gH})
     assert rel(t[0].grad, em) < TOL and rel(t[1].grad, ev) < TOL and rel(t[2].grad, ec) < TOL
+
+
+def test_sample_plans_are_remembered_across_alternating_point_sets(Sampler):
+    """The reference's training step alternates preprocess(collocation points) and
+    preprocess(boundary points) with new Gaussians every step (model_pn.py:766-785): the sorted
+    sample structure of EACH recent tensor is reused, an in-place write invalidates it, and the
+    outputs are those of a sampler that rebuilds everything."""
+    rng = np.random.default_rng(11)
+    pts_a = dev32(rng.uniform(-1, 1, (3000, 2)))
+    pts_b = dev32(rng.uniform(-1.5, 1.5, (1000, 2)))
+    s = Sampler(False, backend="binned")
+    fresh = Sampler(False, backend="binned", reuse_samples=False)
+    seen = {}
+    for step in range(3):
+        means, con, values = random_gaussians(rng, 400, 1)
+        g = [dev32(x) for x in (means, values, con)]
+        for name, pts in (("a", pts_a), ("b", pts_b)):
+            s.preprocess(g[0], g[1], None, g[2], pts)
+            sp = s._plan.samples
+            if name in seen:
+                assert sp is seen[name], "the samples half was rebuilt for a tensor seen one call earlier"
+            seen[name] = sp
+            fresh.preprocess(g[0], g[1], None, g[2], pts)
+            assert fresh._plan.samples is not sp
+            for o, f in zip(s.sample((0, 1, 2)), fresh.sample((0, 1, 2))):
+                # the same sorted order of points and Gaussians up to the order atomics arrived in: last-bit differences
+                assert rel(o, f.cpu().double().numpy()) < 1e-6
+    assert fresh._sample_plans == []
+    pts_a.mul_(1.0)                                   # an in-place write: the version counter moves
+    means, con, values = random_gaussians(rng, 400, 1)
+    s.preprocess(dev32(means), dev32(values), None, dev32(con), pts_a)
+    assert s._plan.samples is not seen["a"]
+    s.preprocess(dev32(means), dev32(values), None, dev32(con), pts_b)
+    assert s._plan.samples is seen["b"]
+    # the memory is bounded: at most ``reuse_samples`` structures are kept
+    s2 = Sampler(False, backend="binned", reuse_samples=2)
+    for k in range(5):
+        s2.preprocess(dev32(means), dev32(values), None, dev32(con), dev32(rng.uniform(-1, 1, (500 + k, 2))))
+    assert len(s2._sample_plans) == 2
