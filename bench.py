@@ -254,6 +254,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
+    host_issue = [0.0]
+
     def timed_steps(step, warmup, steps):
         """W untimed + exactly K timed steps between barrier + synchronize pairs; max over the ranks."""
         for _ in range(warmup):
@@ -262,6 +264,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        host_issue[0] = (time.perf_counter() - t0) / max(steps, 1)      # this rank's host: the loop before the device has drained
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
@@ -284,6 +287,7 @@ def main():
         preheat_ms = (time.perf_counter() - t0) * 1e3
         # ---------------- the headline: K cold steps ----------------
         dt = timed_steps(step, a.warmup, a.steps)
+        host_cold = host_issue[0]
         ms_per_step = dt / a.steps * 1e3
         value = M * world / (dt / a.steps)
         # ---------------- the same with the samples half of the plan reused ----------------
@@ -376,8 +380,10 @@ def main():
         nb = max(1, min(a.steps, 100))
         wb = min(10, nb)        # eager steps settle after a few iterations (caching allocator, autograd graph reuse)
         sampler_only_s = timed_steps(sampler_step, wb, nb) / nb
+        host_sampler_only = host_issue[0]
         fwd_bwd = {"ms_per_step": timed_steps(train_step, wb, nb) / nb * 1e3,
                    "sampler_only_ms_per_step": sampler_only_s * 1e3,
+                   "sampler_only_host_issue_ms_per_step": host_sampler_only * 1e3,
                    "trace_residual_ms_per_step": timed_steps(trace_step, wb, nb) / nb * 1e3, "steps": nb,
                    "value": M * world / sampler_only_s,
                    "dist_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
@@ -457,6 +463,7 @@ def main():
                                f"GPU, d=2, c=1, kappa={a.kappa}, orders 0-2", "gaussians": N, "points_per_gpu": M,
                    "kappa": a.kappa, "path": "binned" if binned else "dense",
                    "step": "preprocess (cold: nothing reused) + fused forward (orders 0..2)"},
+        "host_issue_ms_per_step": host_cold * 1e3,
         "preheat_ms": preheat_ms, "value_warm_plan": warm["value"], "warm_plan": warm,
         "roofline": roofline, "roofline_bwd": roofline_bwd, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
         "kappa_1_3": kappa13,

@@ -77,4 +77,7 @@ def replicated(means, values, conics, group=None):
     same leading dimension N, dtype and device."""
     if not (means.shape[0] == values.shape[0] == conics.shape[0]):
         raise ValueError("means, values and conics must share their leading dimension N")
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        # a single process: nothing to sum, and no autograd node in the eager step's host path either
+        return means, values.reshape(values.shape[0], -1), conics.reshape(conics.shape[0], -1)
     return _Replicated.apply(group, means, values.reshape(values.shape[0], -1), conics.reshape(conics.shape[0], -1))
