@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 4
+#define PIGS_ABI_VERSION 5
 
 enum pigs_status {
     PIGS_OK = 0,
@@ -115,11 +115,21 @@ size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsuppor
 /* samples workspace alone (4 launches) */
 int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream);
 
-/* plan workspace; build_samples != 0 also (re)builds the samples workspace from `samples` in the
- * same launches (5 in all), build_samples == 0 requires a samples workspace that is already
- * built, or being built earlier on the same stream (`samples` is not read then; 5 launches). */
+/* plan workspace.  `flags`:
+ *   PIGS_BUILD_SAMPLES       also (re)builds the samples workspace from `samples` in the same launches
+ *                            (5 in all); without it the samples workspace must be built already, or be
+ *                            being built earlier on the same stream (`samples` is not read then).
+ *   PIGS_BUILD_PLAN_WS_CLEAN the plan workspace's counters are known to be zero: it was the target of
+ *                            an earlier pigs_plan_build with the same (N, M, c) that has completed or
+ *                            precedes this call on the same stream (every build leaves them zeroed),
+ *                            or the caller zero-filled it.  Saves the zeroing launch of a build on an
+ *                            existing samples workspace (4 launches instead of 5); ignored together
+ *                            with PIGS_BUILD_SAMPLES, whose first launch zeroes anyway.
+ * (ABI 4 called this parameter build_samples: 0 / 1 keep their meaning.) */
+#define PIGS_BUILD_SAMPLES 1
+#define PIGS_BUILD_PLAN_WS_CLEAN 2
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
-                    int build_samples, int64_t N, int64_t M, int c, float q_max,
+                    int flags, int64_t N, int64_t M, int c, float q_max,
                     const void* means, const void* conics, const void* values, const void* samples, void* stream);
 
 int pigs_plan_forward(void* workspace, size_t workspace_bytes, const void* samples_ws, size_t samples_ws_bytes,

@@ -364,6 +364,11 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         const uint64_t m = __ballot(occ);
         if (threadIdx.x == 0) a.params->level_mask = (uint32_t)m;
     }
+    if (a.do_plan) {
+        // the scan has consumed the counters and its own flags: leave them zeroed, so that a later
+        // build into this workspace (PIGS_BUILD_PLAN_WS_CLEAN) needs no zeroing launch
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.zero_words; k += gridDim.x * 256) a.counts[k] = 0u;
+    }
     if (gpart && i < a.N) {
         const uint2 kr = a.gkey[i];
         const uint32_t pos = a.starts[kr.x] + kr.y;
@@ -1418,7 +1423,7 @@ static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_
 
 // The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
 // (build_plan) or both in the same four launches, then the tile lists.
-static int run_build(bool do_samples, bool do_plan, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
+static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
                      int64_t M, int c, float q_max, const void* means, const void* conics, const void* values,
                      const void* samples, hipStream_t stream) {
     if (!samples_supported(M)) return PIGS_ERR_UNSUPPORTED;
@@ -1438,7 +1443,7 @@ static int run_build(bool do_samples, bool do_plan, void* sws, size_t sws_bytes,
     clear_hip_error();
     const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
     if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
+    else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 1023) / 1024) : 0u)), dim3(256), 0,
                        stream, a);
     hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? s.scan_blocks : 0u)),
@@ -1458,13 +1463,13 @@ static int run_build(bool do_samples, bool do_plan, void* sws, size_t sws_bytes,
 }
 
 int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream) {
-    return run_build(true, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, nullptr, nullptr, nullptr, samples, stream);
+    return run_build(true, false, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, nullptr, nullptr, nullptr, samples, stream);
 }
 
-int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int build_samples, int64_t N, int64_t M, int c,
+int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags, int64_t N, int64_t M, int c,
                float q_max, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream) {
-    return run_build(build_samples != 0, true, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, means, conics, values,
+    return run_build((flags & 1) != 0, true, (flags & 2) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, means, conics, values,
                      samples, stream);
 }
 

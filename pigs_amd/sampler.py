@@ -111,17 +111,42 @@ class SamplePlan:
             raise _lib.PigsError("samples build: the cell scan timed out waiting for a predecessor workgroup")
 
 
+class _PlanPool:
+    """Plan workspaces whose plan has died, kept for the next ``preprocess`` of the same sizes on the
+    same stream: a build leaves its workspace's counters zeroed, so a build INTO such a workspace
+    skips the zeroing launch (PIGS_BUILD_PLAN_WS_CLEAN).  A workspace is only ever handed out again
+    after its plan object is gone (no autograd node can still read it) and only to the stream its
+    last build ran on (stream order then covers kernels that may still be in flight)."""
+
+    KEEP = 2           # per key; the rest goes back to torch's allocator
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, key):
+        lst = self.free.get(key)
+        return lst.pop() if lst else None
+
+    def give(self, key, workspace):
+        lst = self.free.setdefault(key, [])
+        if len(lst) < self.KEEP:
+            lst.append(workspace)
+
+
 class Plan:
     """The Gaussian half of what ``preprocess`` builds (C ABI: pigs_plan_*): the Gaussians binned
     into the multi-level grid and the per-tile lists, on top of a :class:`SamplePlan`.  Immutable
     once built; autograd nodes keep a reference, so later ``preprocess`` calls never disturb a
     pending backward."""
 
-    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max")
+    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "_pool", "_pool_key")
 
-    def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None):
+    BUILD_SAMPLES, WS_CLEAN = 1, 2      # pigs_amd.h: PIGS_BUILD_SAMPLES, PIGS_BUILD_PLAN_WS_CLEAN
+
+    def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None, pool=None):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
+        self._pool = None
         key = (self.N, self.M, self.c)
         nbytes = _WORKSPACE_BYTES.get(key)
         if nbytes is None:
@@ -131,15 +156,29 @@ class Plan:
         if sample_plan is None:
             sample_plan = SamplePlan(samples, source)
         self.samples = sample_plan
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
-        sws = sample_plan.workspace
         with _on_device(means.device):
+            stream = _stream(means.device)
+            self._pool_key = (self.N, self.M, self.c, means.device, stream.value)
+            self.workspace = pool.take(self._pool_key) if pool is not None else None
+            flags = 0 if sample_plan.built else self.BUILD_SAMPLES
+            if self.workspace is not None:
+                flags |= self.WS_CLEAN
+            else:
+                self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
+            sws = sample_plan.workspace
             rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, _ptr(sws), sws.numel(),
-                                     0 if sample_plan.built else 1, self.N, self.M, self.c, self.q_max,
-                                     _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
-                                     _stream(means.device))
+                                     flags, self.N, self.M, self.c, self.q_max,
+                                     _ptr(means), _ptr(conics), _ptr(values), _ptr(samples), stream)
         _lib.check(rc, "pigs_plan_build")
         sample_plan.built = True
+        self._pool = pool            # only a workspace whose build was launched completely goes back
+
+    def __del__(self):
+        try:
+            if self._pool is not None:
+                self._pool.give(self._pool_key, self.workspace)
+        except Exception:            # interpreter shutdown: nothing to keep
+            pass
 
     def check(self):
         self.samples.check()
@@ -306,6 +345,7 @@ class GaussianSampler:
         self._plan = None
         self._sample_plan = None
         self._sample_plans = []          # most recently used first, at most ``reuse_samples``
+        self._plan_pool = _PlanPool()
         self._samples_source = None
         self._cache = {}
         _lib.load()  # fail at construction, not at first use, if the HIP library is missing
@@ -381,8 +421,11 @@ class GaussianSampler:
         unmodified samples tensor it remembers (``reuse_samples``)."""
         mc, vc, cc, sc = self._inputs
         sp = sample_plan or next((p for p in self._sample_plans if p.matches(self._samples_source)), None)
+        # memory handed out while a hipGraph is being captured belongs to the graph: it neither comes from
+        # the pool nor goes back to it
+        pool = None if torch.cuda.is_current_stream_capturing() else self._plan_pool
         with torch.no_grad():
-            plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source)
+            plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source, pool)
         self._sample_plan = plan.samples
         if self.reuse_samples:
             self._sample_plans = [plan.samples] + [p for p in self._sample_plans if p is not plan.samples]

@@ -442,3 +442,36 @@ def test_sample_plans_are_remembered_across_alternating_point_sets(Sampler):
     for k in range(5):
         s2.preprocess(dev32(means), dev32(values), None, dev32(con), dev32(rng.uniform(-1, 1, (500 + k, 2))))
     assert len(s2._sample_plans) == 2
+
+
+def test_plan_workspaces_are_recycled_only_after_their_plan_died(Sampler):
+    """A build into a workspace whose previous plan is gone skips the zeroing launch
+    (PIGS_BUILD_PLAN_WS_CLEAN: every build leaves its counters zeroed).  Results must not depend on
+    it, a plan that is still referenced must keep its workspace, and plans of other sizes must not
+    be mixed up."""
+    import gc
+    rng = np.random.default_rng(23)
+    pts = dev32(rng.uniform(-1, 1, (4000, 2)))
+    s = Sampler(False, backend="binned")
+    dense = Sampler(False, backend="dense")
+    kept = []
+    ptrs = set()
+    for step in range(8):
+        N = 300 if step % 3 else 500                      # two sizes alternate: two pool keys
+        means, con, values = random_gaussians(rng, N, 1)
+        g = [dev32(x) for x in (means, values, con)]
+        s.preprocess(g[0], g[1], None, g[2], pts)
+        plan = s._plan
+        for k in kept:                                      # a live plan's workspace is never handed out again
+            assert plan.workspace.data_ptr() != k.workspace.data_ptr()
+        if step == 2:
+            kept.append(plan)                               # as an autograd node would
+        ptrs.add(plan.workspace.data_ptr())
+        dense.preprocess(g[0], g[1], None, g[2], pts)
+        for o, e in zip(s.sample((0, 1, 2)), dense.sample((0, 1, 2))):
+            assert rel(o, e.cpu().double().numpy()) < TOL
+        del plan
+        gc.collect()
+    assert len(ptrs) < 8, "no workspace was ever reused"
+    # the kept plan still answers for ITS Gaussians after all the rebuilding around it
+    assert kept[0].N == 300
