@@ -970,6 +970,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
     if (tile >= sv.ntiles) return;
+    __builtin_amdgcn_s_setprio(3);
     FwdLds& lds = lds_all[wave];
     char* const qbase = (char*)lds.rec;
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
@@ -1003,7 +1004,11 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         }
         wave_lds_fence();
 #ifndef PIGS_DEBUG_SKIP_EVAL
+        // waves outside the row loop (issuing loads, filling queues, storing) go first: their memory
+        // requests are what the others' arithmetic hides (27.5 -> 27.3 us; the other way round 28.1)
+        __builtin_amdgcn_s_setprio(0);
         evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
+        __builtin_amdgcn_s_setprio(3);
 #else
         acc[0] += (float)rows + ((const float*)lds.rec)[lane];
 #endif
