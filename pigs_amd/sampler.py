@@ -118,19 +118,31 @@ class _PlanPool:
     after its plan object is gone (no autograd node can still read it) and only to the stream its
     last build ran on (stream order then covers kernels that may still be in flight)."""
 
-    KEEP = 2           # per key; the rest goes back to torch's allocator
+    KEEP = 2           # per key (sizes, device, stream)
+    KEEP_TOTAL = 4     # over all keys: problem sizes that change from step to step must not pile up workspaces
 
     def __init__(self):
-        self.free = {}
+        self.free = {}             # key -> [workspace, ...]; dict order = least recently given first
 
     def take(self, key):
         lst = self.free.get(key)
-        return lst.pop() if lst else None
+        if not lst:
+            return None
+        ws = lst.pop()
+        if not lst:
+            del self.free[key]
+        return ws
 
     def give(self, key, workspace):
-        lst = self.free.setdefault(key, [])
+        lst = self.free.pop(key, [])
         if len(lst) < self.KEEP:
             lst.append(workspace)
+        self.free[key] = lst       # most recently given last
+        while sum(len(v) for v in self.free.values()) > self.KEEP_TOTAL:
+            oldest = next(iter(self.free))
+            self.free[oldest].pop(0)
+            if not self.free[oldest]:
+                del self.free[oldest]
 
 
 class Plan:
