@@ -64,7 +64,7 @@ constexpr uint32_t LIST_IDX_MASK = (1u << LIST_IDX_BITS) - 1u;
 // tile header, 8 words: [0] = count | mode << 30 (entries of the tile list, or record ranges), [1..4] =
 // lengths of the four group lists (list mode)
 constexpr int TILE_HDR_WORDS = 8;
-constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u;
+constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u, TILE_MODE_GROUPS = 2u;
 constexpr int TILE_MODE_SHIFT = 30;
 constexpr uint32_t TILE_COUNT_MASK = (1u << TILE_MODE_SHIFT) - 1u;
 
@@ -270,11 +270,24 @@ __device__ inline SampleGrid sample_grid(const float* box, uint32_t M, uint32_t 
     return s;
 }
 
-// cell id ordered block (4x4 cells) > 2x2 > cell: the 16 cells of a block, and inside it the four
-// cells of each 2x2, are consecutive -- so are their points in the sorted array
+// Cell ids follow a path through the grid whose consecutive cells are neighbours (almost) everywhere:
+// tiles and groups are runs of 64 / 16 consecutive sorted points, and where cells do not hold
+// exactly 16 points (any point set but a lattice) a run straddles consecutive cells -- with a
+// row-major order of blocks that meant, at the end of every block row, groups whose box spanned the
+// whole domain (random points at C3: 56 tiles fell back to record ranges and one launch took
+// 395 us instead of 45).  The path: blocks of 4 x 4 cells, block rows taken in turn left to right
+// and right to left; inside a block the order-2 Hilbert curve from the bottom corner the path
+// enters at to the other bottom corner (mirrored in the right-to-left rows).  Any 4 consecutive
+// cells starting at a multiple of 4 are a 2 x 2 quad, any 16 at a multiple of 16 a block: on a
+// lattice with 4 x 4 points per cell a tile is an 8 x 8 patch, four consecutive tiles 16 x 16.
 __device__ inline uint32_t sample_cell_id(int cx, int cy, int nx) {
-    const uint32_t block = (uint32_t)((cy >> 2) * (nx >> 2) + (cx >> 2));
-    const uint32_t in = (uint32_t)((((cy >> 1) & 1) << 3) | (((cx >> 1) & 1) << 2) | ((cy & 1) << 1) | (cx & 1));
+    const int nbx = nx >> 2, bx = cx >> 2, by = cy >> 2;
+    const bool back = (by & 1) != 0;
+    const uint32_t block = (uint32_t)(by * nbx + (back ? nbx - 1 - bx : bx));
+    const int lx = back ? 3 - (cx & 3) : (cx & 3), ly = cy & 3;
+    // Hilbert index of (lx, ly) in the 4 x 4 block, one nibble per cell, cell (lx, ly) at nibble ly * 4 + lx:
+    // (0,0) (1,0) (1,1) (0,1) (0,2) (0,3) (1,3) (1,2) (2,2) (2,3) (3,3) (3,2) (3,1) (2,1) (2,0) (3,0)
+    const uint32_t in = (uint32_t)(0xA965B874CD23FE10ull >> (4 * (ly * 4 + lx))) & 15u;
     return (block << 4) | in;
 }
 

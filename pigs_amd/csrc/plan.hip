@@ -685,10 +685,10 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
 
     const uint32_t cap = pv.list_cap;
     uint32_t n[LISTS_TPW], ng[LISTS_TPW][4];
-    bool overflow[LISTS_TPW];
+    bool overflow[LISTS_TPW], goverflow[LISTS_TPW];       // the tile list / one of the group lists is full
 #pragma unroll
     for (int t = 0; t < LISTS_TPW; ++t) {
-        n[t] = 0; overflow[t] = false;
+        n[t] = 0; overflow[t] = false; goverflow[t] = false;
 #pragma unroll
         for (int g = 0; g < 4; ++g) ng[t][g] = 0;
     }
@@ -750,8 +750,10 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
                     const uint32_t cg = (uint32_t)__builtin_popcountll(mg);
                     if (ng[t][g] + cg <= cap) {
                         if (gm >> g & 1u) gl[g * cap + ng[t][g] + (uint32_t)lanes_below(mg)] = j;
+                    } else {
+                        goverflow[t] = true;
                     }
-                    ng[t][g] += cg;     // a group list is never longer than the tile list: overflow is caught above
+                    ng[t][g] += cg;
                 }
             }
             wave_lds_fence();
@@ -772,14 +774,19 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     });
     if (sn > 0) flush();
 
+    // A tile list that does not fit while the four group lists do (64 scattered points of a sparse
+    // region share few Gaussians: up to 4 x cap distinct ones) is no reason to give the lists up: the
+    // forward reads the group lists only, and the backward walks them as four single-group lists.
     bool any_overflow = false;
 #pragma unroll
     for (int t = 0; t < LISTS_TPW; ++t) {
         if (tile0 + (uint32_t)t >= ntiles) continue;
+        overflow[t] = overflow[t] && goverflow[t];        // from here on: the tile needs the ranges fallback
         any_overflow |= overflow[t];
         if (!overflow[t] && lane < TILE_HDR_WORDS) {
+            const bool fits = n[t] <= cap;
             uint32_t w = 0;
-            if (lane == 0) w = n[t] | (TILE_MODE_LIST << TILE_MODE_SHIFT);
+            if (lane == 0) w = fits ? (n[t] | (TILE_MODE_LIST << TILE_MODE_SHIFT)) : (TILE_MODE_GROUPS << TILE_MODE_SHIFT);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (lane == 1 + g) w = ng[t][g];
@@ -787,35 +794,41 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         }
     }
     if (!any_overflow) return;
-    // A list does not fit: that tile keeps the grid's record ranges around the wave's tiles instead
-    // (pairs {first, length}); when even those do not fit, the single range of all Gaussians.
-    uint32_t nr = 0;
-    bool fits = true;
-    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.trav, false,
-             [&](int nrow, uint32_t jb, uint32_t len) {
-        const bool keep = lane < nrow && len > 0;
-        const uint64_t km = __ballot(keep);
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
-        if (2 * (nr + cnt) <= cap) {
-            if (keep) {
-                const uint32_t p = 2 * (nr + (uint32_t)lanes_below(km));
+    // A group list does not fit: that tile keeps the grid's record ranges around ITS box instead (pairs
+    // {first, length}; every Gaussian in them is evaluated for all of its points); when even those do
+    // not fit, the single range of all Gaussians.  A rare path: one tile at a time, not unrolled.
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        const bool mine = __builtin_amdgcn_readfirstlane((int)(t == 0   ? overflow[0]
+                                                               : t == 1 ? overflow[LISTS_TPW > 1 ? 1 : 0]
+                                                               : t == 2 ? overflow[LISTS_TPW > 2 ? 2 : 0]
+                                                                        : overflow[LISTS_TPW > 3 ? 3 : 0])) != 0;
+        if (!mine) continue;
+        float4 gb[4];
 #pragma unroll
-                for (int t = 0; t < LISTS_TPW; ++t) {
-                    if (!overflow[t]) continue;
-                    uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+        for (int g = 0; g < 4; ++g) gb[g] = lds.gbox[t * 4 + g];
+        const float tx0 = fminf(fminf(gb[0].x, gb[1].x), fminf(gb[2].x, gb[3].x));
+        const float ty0 = fminf(fminf(gb[0].y, gb[1].y), fminf(gb[2].y, gb[3].y));
+        const float tx1 = fmaxf(fmaxf(gb[0].z, gb[1].z), fmaxf(gb[2].z, gb[3].z));
+        const float ty1 = fmaxf(fmaxf(gb[0].w, gb[1].w), fmaxf(gb[2].w, gb[3].w));
+        uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+        uint32_t nr = 0;
+        bool fits = true;
+        traverse(pv, gg, level_mask, loff, tx0, ty0, tx1, ty1, lane, lds.trav, false,
+                 [&](int nrow, uint32_t jb, uint32_t len) {
+            const bool keep = lane < nrow && len > 0;
+            const uint64_t km = __ballot(keep);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
+            if (2 * (nr + cnt) <= cap) {
+                if (keep) {
+                    const uint32_t p = 2 * (nr + (uint32_t)lanes_below(km));
                     tl[p] = jb; tl[p + 1] = len;
                 }
+            } else {
+                fits = false;
             }
-        } else {
-            fits = false;
-        }
-        nr += cnt;
-    },
-             [](const float4, const float4, uint64_t, uint32_t) {});
-#pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) {
-        if (!overflow[t]) continue;
-        uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+            nr += cnt;
+        },
+                 [](const float4, const float4, uint64_t, uint32_t) {});
         if (!fits && lane == 0) { tl[0] = 0; tl[1] = pv.N; }
         const uint32_t cnt = fits ? nr : 1u;
         if (lane < TILE_HDR_WORDS)
@@ -848,6 +861,17 @@ __device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile,
             const bool have = lane < STEP && e0 + (uint32_t)lane < count;
             const uint32_t e = have ? slab[e0 + lane] : 0u;
             step(e & LIST_IDX_MASK, e >> LIST_IDX_BITS, have);
+        }
+    } else if ((hdr >> TILE_MODE_SHIFT) == TILE_MODE_GROUPS) {
+        // the four group lists, one after the other, as lists of single-group entries (a Gaussian that
+        // reaches two groups comes twice, each time for one of them)
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint32_t ng = pv.hdr[(size_t)tile * TILE_HDR_WORDS + 1 + g];
+            const uint32_t* gl = pv.glist + ((size_t)tile * 4 + g) * pv.list_cap;
+            for (uint32_t e0 = 0; e0 < ng; e0 += STEP) {
+                const bool have = lane < STEP && e0 + (uint32_t)lane < ng;
+                step(have ? gl[e0 + lane] : 0u, have ? 1u << g : 0u, have);
+            }
         }
     } else {
         for (uint32_t r = 0; r < count; ++r) {
@@ -1013,7 +1037,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         acc[0] += (float)rows + ((const float*)lds.rec)[lane];
 #endif
     };
-    if ((h0 >> TILE_MODE_SHIFT) == TILE_MODE_LIST) {
+    if ((h0 >> TILE_MODE_SHIFT) != TILE_MODE_RANGES) {                    // LIST or GROUPS: the group lists are there
         const uint32_t ng = hd[1 + g];                                    // this row's list length
         const uint32_t* gl = pv.glist + ((size_t)tile * 4 + g) * pv.list_cap;
         uint32_t nmax = hd[1] > hd[2] ? hd[1] : hd[2];

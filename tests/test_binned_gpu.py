@@ -62,12 +62,13 @@ def check_case(Sampler, means, con, values, samples, orders=(0, 1, 2, 3), bwd=Tr
         rs[o] = dev32(rng.uniform(-1, 1, exp[o].shape))
         loss = loss + (out * rs[o]).sum()
     if not bwd:
-        return
+        return s
     loss.backward()
     em, ec, ev = c_oracle.backward(*args, {o: r.cpu().double().numpy() for o, r in rs.items()})
     assert rel(t[0].grad, em) < gtol, ("means", rel(t[0].grad, em))
     assert rel(t[1].grad, ev) < gtol, ("values", rel(t[1].grad, ev))
     assert rel(t[2].grad, ec) < gtol, ("conics", rel(t[2].grad, ec))
+    return s
 
 
 @pytest.mark.parametrize("N,M,c", [(1, 1, 1), (7, 3, 2), (500, 2000, 1), (3000, 5000, 2), (2048, 4096, 2)])
@@ -475,3 +476,19 @@ def test_plan_workspaces_are_recycled_only_after_their_plan_died(Sampler):
     assert len(ptrs) < 8, "no workspace was ever reused"
     # the kept plan still answers for ITS Gaussians after all the rebuilding around it
     assert kept[0].N == 300
+
+
+def test_sparse_scattered_points_keep_their_group_lists(Sampler):
+    """Points far apart from each other (the thin outskirts of a clustered cloud) share no Gaussians:
+    a tile of 64 of them meets more than the tile list holds while its four group lists still fit.
+    Such tiles keep their group lists (forward) and the backward walks those; results as ever."""
+    rng = np.random.default_rng(31)
+    N = 8000
+    means, con, values = random_gaussians(rng, N, 1, log_sigma_mean=-4.6, log_sigma_std=0.2)
+    core = rng.normal(0, 0.02, (60000, 2))                       # a dense core sets the cell size ...
+    far = rng.uniform(-1, 1, (1500, 2))                          # ... and the rest is scattered thinly
+    samples = np.clip(np.concatenate((core, far)), -1, 1)
+    s = check_case(Sampler, means, con, values, samples, orders=(0, 1, 2), tol=TOL, gtol=2e-5)
+    from tools.prof_step import list_stats
+    st = list_stats(s._plan)
+    assert st["groups_only_tiles"] > 0, st                       # the case is what it claims to be

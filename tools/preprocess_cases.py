@@ -24,19 +24,29 @@ elif case == "clustered":
 else:
     raise SystemExit("unknown case")
 pts = pts.cuda()
-s = GaussianSampler(False, backend="binned")
+res = {}
+with torch.no_grad():
+    for name, reuse in (("cold", False), ("warm", True)):
+        s = GaussianSampler(False, fuse="all", backend="binned", reuse_samples=reuse)
 
+        def step():
+            s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+            return s.sample((0, 1, 2))
 
-def step():
-    s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
-    return s.sample((0, 1, 2))
-
-
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(20):
-    step()
-torch.cuda.synchronize()
-print(f"{case} kappa={kappa}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us/step", flush=True)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.25:          # untimed pre-heat, as bench.py
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / 100 * 1e6
+    from pigs_amd import sampler as S
+    m, v, c, sm = s._inputs
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        S.forward_raw(m, v, c, sm, 7, s._plan)
+    e1.record(); torch.cuda.synchronize()
+print(f"{case:9s} kappa={kappa}: cold {res['cold']:7.1f} us/step  warm {res['warm']:7.1f} us/step  forward kernel {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us", flush=True)
