@@ -141,14 +141,22 @@ __device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, 
 // Expand the symmetric accumulators into the reference layouts
 //   out0[M][c], out1[M][d][c], out2[M][d][d][c], out3[M][d][d][d][c]
 // for point m.  Null output pointers are skipped (the order was computed but not requested).
-template <typename T, int D, int C, int MASK>
+// STREAM: non-temporal stores (`nt`): outputs that nothing in the launch reads again leave the L2 as
+// they are written instead of staying dirty until the end-of-kernel write-back (the binned forward at
+// C3 writes 24 MB: 28.0 -> 26.6 us); the dense kernels' small outputs stay cacheable for the consumer.
+template <bool STREAM, typename T>
+__device__ __forceinline__ void store_out(T* p, T v) {
+    if constexpr (STREAM) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <typename T, int D, int C, int MASK, bool STREAM = false>
 __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict__ o0, T* __restrict__ o1,
                                           T* __restrict__ o2, T* __restrict__ o3) {
     using L = FwdLayout<D, C, MASK>;
     if constexpr ((MASK & ORD0) != 0) {
         if (o0) {
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) o0[m * C + ch] = acc[L::O0 + ch];
+            for (int ch = 0; ch < C; ++ch) store_out<STREAM>(&o0[m * C + ch], acc[L::O0 + ch]);
         }
     }
     if constexpr ((MASK & ORD1) != 0) {
@@ -156,7 +164,7 @@ __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) o1[(m * D + i) * C + ch] = -acc[L::O1 + i * C + ch];
+                for (int ch = 0; ch < C; ++ch) store_out<STREAM>(&o1[(m * D + i) * C + ch], -acc[L::O1 + i * C + ch]);
         }
     }
     if constexpr ((MASK & ORD2) != 0) {
@@ -167,13 +175,13 @@ __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict
                 for (int j = 0; j < D; ++j)
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch)
-                        o2[((m * D + i) * D + j) * C + ch] = acc[L::O2 + (i + j) * C + ch];  // D<=2: sym index = i+j
+                        store_out<STREAM>(&o2[((m * D + i) * D + j) * C + ch], acc[L::O2 + (i + j) * C + ch]);  // D<=2: sym index = i+j
         }
     }
     if constexpr ((MASK & ORD2T) != 0) {      // trace: out2 is [M][c]
         if (o2) {
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) o2[m * C + ch] = acc[L::O2 + ch];
+            for (int ch = 0; ch < C; ++ch) store_out<STREAM>(&o2[m * C + ch], acc[L::O2 + ch]);
         }
     }
     if constexpr ((MASK & ORD3) != 0) {
@@ -186,7 +194,7 @@ __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict
                     for (int k = 0; k < D; ++k)
 #pragma unroll
                         for (int ch = 0; ch < C; ++ch)
-                            o3[(((m * D + i) * D + j) * D + k) * C + ch] = acc[L::O3 + (i + j + k) * C + ch];
+                            store_out<STREAM>(&o3[(((m * D + i) * D + j) * D + k) * C + ch], acc[L::O3 + (i + j + k) * C + ch]);
         }
     }
 }

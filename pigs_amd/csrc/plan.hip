@@ -1075,10 +1075,10 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
                 float* dst = o2 + (size_t)sp.m * 4;
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(h) : "memory");
             }
-            fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, nullptr, o3);
+            fwd_store<float, 2, C, MASK, true>(acc, (int64_t)sp.m, o0, o1, nullptr, o3);
         } else
 #endif
-        fwd_store<float, 2, C, MASK>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+        fwd_store<float, 2, C, MASK, true>(acc, (int64_t)sp.m, o0, o1, o2, o3);
     }
 }
 
