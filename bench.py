@@ -24,6 +24,7 @@ VALU-issue figure beside it, roofline_bwd, cpu_baseline (the reference's dense P
 the host cores, bounded sample).
 """
 import argparse
+import gc
 import ctypes
 import json
 import math
@@ -261,12 +262,20 @@ def main():
         for _ in range(warmup):
             step()
         barrier()
+        # Python's cyclic collector stays out of the timed region: a full collection of a process that has
+        # imported torch walks ~10^6 objects and takes 35-45 ms (tools/stall_probe.py: one step in ~900),
+        # more than the K steps together.  Reference counting still frees every tensor at once.
+        gc_was_on = gc.isenabled()
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         host_issue[0] = (time.perf_counter() - t0) / max(steps, 1)      # this rank's host: the loop before the device has drained
         barrier()
-        return max_over_ranks(time.perf_counter() - t0)
+        dt = max_over_ranks(time.perf_counter() - t0)
+        if gc_was_on:
+            gc.enable()
+        return dt
 
     def forward_only(tt, pp, reuse):
         smp = GaussianSampler(False, fuse="all", backend=a.backend, reuse_samples=reuse)
@@ -302,11 +311,13 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn()
         torch.cuda.synchronize(dev)
+        gc.disable()                    # a collector pause on the host would leave the device idle between the events
         e0.record()
         for _ in range(n):
             fn()
         e1.record()
         torch.cuda.synchronize(dev)
+        gc.enable()
         return e0.elapsed_time(e1) / n
 
     def roofline_of(smp, kappa):
@@ -434,10 +445,12 @@ def main():
                 st.wait_stream(torch.cuda.current_stream(dev))
             run2(max(2, a.warmup))
             barrier()
+            gc.disable()
             t0 = time.perf_counter()
             run2(a.steps)
             barrier()
             dt2 = max_over_ranks(time.perf_counter() - t0)
+            gc.enable()
         two_streams = {"ms_per_step": dt2 / a.steps * 1e3, "value": M * world / (dt2 / a.steps),
                        "what": "the same K cold steps issued round-robin on two HIP streams (one sampler per stream)"}
         del keep, samplers2
