@@ -492,3 +492,14 @@ def test_sparse_scattered_points_keep_their_group_lists(Sampler):
     from tools.prof_step import list_stats
     st = list_stats(s._plan)
     assert st["groups_only_tiles"] > 0, st                       # the case is what it claims to be
+
+
+def test_backward_tile_shuffle_with_a_partial_last_chunk(Sampler):
+    """The backward deals the tiles of every full chunk of 1024 out in a shuffled order and leaves a
+    trailing partial chunk in launch order: a size with one full chunk and a ragged rest (and a last
+    tile that is not full) against the oracle."""
+    rng = np.random.default_rng(41)
+    M = 1024 * 64 + 70 * 64 + 37
+    means, con, values = random_gaussians(rng, 1500, 1, log_sigma_mean=-3.2, log_sigma_std=0.4)
+    samples = rng.uniform(-1, 1, (M, 2))
+    check_case(Sampler, means, con, values, samples, orders=(0, 1, 2), gtol=2e-5)
