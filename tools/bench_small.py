@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pigs_amd import synthetic
 from diff_gaussian_sampling import GaussianSampler
+import gc
+gc.collect(); gc.freeze()      # a full collection of a torch process takes 35-45 ms: keep it out of the short timed loops
 
 
 def make_case(n, M):
