@@ -268,14 +268,24 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
 
 class _SampleFunction(torch.autograd.Function):
     """One fused launch producing the outputs of every order in ``mask``; its backward is one
-    fused launch over the outputs that received a gradient."""
+    fused launch over the outputs that received a gradient.
+
+    The reference's scripts treat the outputs of the separate ``sample_*`` calls as independent graphs:
+    they differentiate one component after the other, some calls with ``retain_graph=True`` and the
+    last one on an output without (test_derivatives.py:214-215), and come back to another output of
+    the same ``preprocess`` later (test_derivatives.py:349-352).  Outputs that were computed by ONE
+    fused launch share this node, so the node must survive a backward that does not retain the graph:
+    the inputs are therefore kept on the node itself rather than through ``save_for_backward`` (whose
+    storage autograd releases after the first such backward), with the version check that
+    ``save_for_backward`` would have done repeated by hand."""
 
     @staticmethod
     def forward(ctx, means, values, conics, samples, mask, debug, plan):
         outs = forward_raw(means, values, conics, samples, mask, plan)
         if debug:
             torch.cuda.synchronize(means.device)
-        ctx.save_for_backward(means, values, conics, samples)
+        ctx.inputs = (means, values, conics, samples)
+        ctx.versions = (means._version, values._version, conics._version, samples._version)
         ctx.mask = mask
         ctx.debug = debug
         ctx.plan = plan
@@ -285,7 +295,10 @@ class _SampleFunction(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grad_outputs):
-        means, values, conics, samples = ctx.saved_tensors
+        means, values, conics, samples = ctx.inputs
+        if (means._version, values._version, conics._version, samples._version) != ctx.versions:
+            raise RuntimeError("one of the tensors handed to GaussianSampler.preprocess() has been modified in place "
+                               "before the backward of a sample_*() output that was computed from it")
         gouts = [None] * 5
         mask = 0
         for k, g in zip(_mask_orders(ctx.mask), grad_outputs):

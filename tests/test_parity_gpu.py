@@ -244,3 +244,46 @@ def test_config1_1d_256x4096(Sampler):
                            t["values"].cpu().double().numpy(), pts.float().double().numpy(), orders=(0, 1, 2))
     for o, out in enumerate(outs):
         assert rel(out, exp[o]) < F32_TOL
+
+
+@pytest.mark.parametrize("backend", ["dense", "binned"])
+def test_reference_autograd_call_patterns(Sampler, backend):
+    """The calls the reference's own scripts make on the sampler's outputs (test_derivatives.py:123,
+    214-215, 349-352): ``autograd.grad`` with ``retain_graph=True`` and ``create_graph=True`` on the
+    order-0 output, then one component of the derivative / Hessian outputs at a time on the same graph
+    (the node runs its backward again and again), the last call without retaining."""
+    rng = np.random.default_rng(77)
+    N, M = 60, 900
+    means = rng.uniform(-1, 1, (N, 2))
+    s = np.exp(rng.normal(-3.0, 0.3, (N, 2)))
+    con = np.stack((1 / s[:, 0], np.zeros(N), 1 / s[:, 1]), -1)
+    values = rng.uniform(0, 1, (N, 1))
+    pts = rng.uniform(-1, 1, (M, 2))
+    t = [dev(a, torch.float32) for a in (means, values, con, pts)]
+    for x in t[:3]:
+        x.requires_grad_(True)
+    smp = Sampler(True, backend=backend)
+    smp.preprocess(t[0], t[1], None, t[2], t[3])
+    args = [x.detach().cpu().double().numpy() for x in (t[0], t[2], t[1], t[3])]
+
+    def expect(order, comp):
+        shape = {0: (M, 1), 1: (M, 2, 1), 2: (M, 2, 2, 1)}[order]
+        r = np.zeros(shape)
+        r[(slice(None),) + comp] = 1.0
+        gm, gc, gv = c_oracle.backward(*args, {order: r})
+        return gm, gv, gc
+
+    def check(got, exp, what):
+        for g, e, name in zip(got, exp, ("means", "values", "conics")):
+            assert rel(g, e) < 3e-5, (what, name, rel(g, e))
+
+    u = smp.sample_gaussians()
+    check(torch.autograd.grad(u.sum(), t[:3], retain_graph=True, create_graph=True), expect(0, ()), "order 0")
+    ux = smp.sample_gaussians_derivative().squeeze()
+    check(torch.autograd.grad(ux[..., 0].sum(), t[:3], retain_graph=True), expect(1, (0,)), "d/dx")
+    check(torch.autograd.grad(ux[..., 1].sum(), t[:3]), expect(1, (1,)), "d/dy")
+    h = smp.sample_gaussians_laplacian().squeeze()
+    check(torch.autograd.grad(h[..., 0, 0].sum(), t[:3], retain_graph=True), expect(2, (0, 0)), "xx")
+    check(torch.autograd.grad(h[..., 0, 1].sum(), t[:3], retain_graph=True), expect(2, (0, 1)), "xy")
+    check(torch.autograd.grad(h[..., 1, 0].sum(), t[:3], retain_graph=True), expect(2, (1, 0)), "yx")
+    check(torch.autograd.grad(h[..., 1, 1].sum(), t[:3]), expect(2, (1, 1)), "yy")
