@@ -19,8 +19,9 @@ elif case == "random":
 elif case == "shuffled":
     pts = synthetic.grid_samples(1024).float()
     pts = pts[torch.randperm(pts.shape[0], generator=g)]
-elif case == "clustered":
-    pts = (torch.randn((1 << 20, 2), generator=g) * 0.15).clamp(-1, 1)
+elif case.startswith("clustered"):       # clustered, or clustered:<sigma> (test_no_mlp.py:86 draws randn / 2, clamped)
+    sigma = float(case.split(":")[1]) if ":" in case else 0.15
+    pts = (torch.randn((1 << 20, 2), generator=g) * sigma).clamp(-1, 1)
 else:
     raise SystemExit("unknown case")
 pts = pts.cuda()
