@@ -285,6 +285,16 @@ def main():
             return smp.sample((0, 1, 2))
         return smp, step
 
+    def settle(fn, seconds=0.05):
+        """Untimed steps of a NEW sampler before its timed ones: its first workspaces come from fresh
+        allocations, and an occasional stall of tens of milliseconds was seen within the first dozens of
+        steps behind them (profiles/README.md); a few hundred untimed steps keep it out of the measurement."""
+        t0_ = time.perf_counter()
+        while time.perf_counter() - t0_ < seconds:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize(dev)
+
     # ---------------- untimed pre-heat: a short --steps run must not time a chip that is still ramping ----------------
     sampler, step = forward_only(t, pts_d, False)
     with torch.no_grad():
@@ -301,6 +311,7 @@ def main():
         value = M * world / (dt / a.steps)
         # ---------------- the same with the samples half of the plan reused ----------------
         sampler_w, step_w = forward_only(t, pts_d, True)
+        settle(step_w)
         dtw = timed_steps(step_w, a.warmup, a.steps)
         warm = {"value": M * world / (dtw / a.steps), "ms_per_step": dtw / a.steps * 1e3,
                 "what": "the same K steps with preprocess() handed the same unmodified samples tensor every time: the "
@@ -444,6 +455,7 @@ def main():
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream(dev))
             run2(max(2, a.warmup))
+            settle(lambda: run2(2))
             barrier()
             gc.disable()
             t0 = time.perf_counter()
@@ -461,6 +473,7 @@ def main():
             s13, step13 = forward_only(t13, pts_d, False)
             with torch.no_grad():
                 n13 = max(5, a.steps // 4)
+                settle(step13)
                 d13 = timed_steps(step13, 3, n13)
             r13 = roofline_of(s13, 1.3)
             kappa13 = {"value": M * world / (d13 / n13), "ms_per_step": d13 / n13 * 1e3, "steps": n13,
