@@ -286,9 +286,8 @@ def main():
         return smp, step
 
     def settle(fn, seconds=0.05):
-        """Untimed steps of a NEW sampler before its timed ones: its first workspaces come from fresh
-        allocations, and an occasional stall of tens of milliseconds was seen within the first dozens of
-        steps behind them (profiles/README.md); a few hundred untimed steps keep it out of the measurement."""
+        """Untimed steps of a NEW sampler before its timed ones: its first steps allocate and first-touch
+        fresh workspaces; a few hundred untimed steps keep that out of the measurement (profiles/README.md)."""
         t0_ = time.perf_counter()
         while time.perf_counter() - t0_ < seconds:
             for _ in range(10):
