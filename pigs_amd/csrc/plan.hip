@@ -854,9 +854,12 @@ __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
 }
 
 // Walks a tile's list (or its ranges): `step(idx, gm, have)` for every STEP entries (lane = entry; the
-// lanes from STEP on hold none).
-template <int STEP, typename Step>
-__device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step) {
+// lanes from STEP on hold none).  A tile in ranges mode has no masks: `ranges_mask()` is called once and
+// returns the functor `mask(idx, have)` that finds an entry's (the caller's kernel keeps its `step` free
+// of that rare case).
+template <int STEP, typename Step, typename RangesMask>
+__device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step,
+                                              RangesMask&& ranges_mask) {
     const uint32_t hdr = pv.hdr[(size_t)tile * TILE_HDR_WORDS];
     const uint32_t count = hdr & TILE_COUNT_MASK;
     const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
@@ -878,11 +881,13 @@ __device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile,
             }
         }
     } else {
+        auto mask = ranges_mask();
         for (uint32_t r = 0; r < count; ++r) {
             const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
             for (uint32_t o = 0; o < len; o += STEP) {
                 const bool have = lane < STEP && o + (uint32_t)lane < len;
-                step(have ? j0 + o + (uint32_t)lane : j0, have ? 0xFu : 0u, have);
+                const uint32_t idx = have ? j0 + o + (uint32_t)lane : j0;
+                step(idx, mask(idx, have), have);
             }
         }
     }
@@ -1057,15 +1062,56 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
             });
         }
     } else {
+        // Record ranges (a group list did not fit): the ranges hold every Gaussian near the tile.  Every
+        // row tests them, 16 at a time, against the box of ITS group and packs the hits into its queue;
+        // the queues are evaluated when one could overflow, and at the end.  With scattered points
+        // (which is when lists overflow) a row keeps a small part of what the ranges hold.
         const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
         const uint32_t count = h0 & TILE_COUNT_MASK;
+        const float INF = __builtin_huge_valf();
+        float x0 = valid ? sp.x : INF, x1 = valid ? sp.x : -INF, y0 = valid ? sp.y : INF, y1 = valid ? sp.y : -INF;
+        row_box_dpp(x0, x1, y0, y1);                  // every lane: the box of its own row's group
+        const bool row_has_points = x0 <= x1;
+        float4* const q = (float4*)(qbase + g * FwdLds::GSTRIDE);
+        int qn = 0;                                    // records in this row's queue (the same in its 16 lanes)
+        auto drain = [&]() {
+            // rows = the longest queue, the others padded with all-zero records
+            int rows = qn;
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) rows = max(rows, __shfl_xor(rows, o));
+            rows = __builtin_amdgcn_readfirstlane((rows + U - 1) / U * U);
+            wave_lds_fence();
+            for (int k = qn + i; k < rows; k += 16) {
+                q[2 * k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                q[2 * k + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            wave_lds_fence();
+            if (rows > 0) {
+                __builtin_amdgcn_s_setprio(0);
+                evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
+                __builtin_amdgcn_s_setprio(3);
+            }
+            qn = 0;
+        };
         for (uint32_t r = 0; r < count; ++r) {
             const uint32_t j0 = slab[2 * r], len = slab[2 * r + 1];
-            for (uint32_t base = 0; base < len; base += GROUP_CAP) {
-                const int rows = (int)(len - base < GROUP_CAP ? len - base : GROUP_CAP);
-                chunk(rows, [&](int p) { return base + p < len ? j0 + base + p : pv.N; });
+            for (uint32_t base = 0; base < len; base += 16) {
+                const bool in = base + (uint32_t)i < len;
+                const size_t j = in ? j0 + base + (uint32_t)i : pv.N;
+                const float4 A = pv.rec[2 * j], B = pv.rec[2 * j + 1];
+                const bool hit = in && row_has_points && ellipse_reaches_rect(ellipse_of(A, B.x), x0, y0, x1, y1, pv.q_max);
+                const uint32_t rm = (uint32_t)(__ballot(hit) >> (16 * g)) & 0xffffu;      // this row's hits
+                if (hit) {
+                    const int k = qn + __builtin_popcount(rm & ((1u << i) - 1u));
+                    q[2 * k] = A;
+                    *(float2*)(q + 2 * k + 1) = make_float2(B.x, B.y);
+                    if constexpr (C == 2) *(float2*)((char*)(q + 2 * k + 1) + 8) = make_float2(B.z, 0.f);
+                }
+                qn += __builtin_popcount(rm);
+                if (__any(qn > GROUP_CAP - 16)) drain();
             }
         }
+        drain();
     }
     // The outputs go back through the points' original indices.  Where those run in the caller's order
     // (a grid: runs of 4 or more consecutive points per cell row) a tile's stores fill whole 32..128-byte
@@ -1293,6 +1339,29 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
         }
     }
     if (lane < 2) lds.t.rec[BWD_STEP][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // A tile that fell back to record ranges has no masks: they are found entry by entry against the
+    // boxes of its four groups (a range holds every Gaussian NEAR the tile; few reach a given group when
+    // the tile's points are scattered, which is when lists overflow).  Built only when the walk meets
+    // such a tile, and outside `step`.
+    auto ranges_mask = [&]() {
+        const float INF = __builtin_huge_valf();
+        float x0 = valid ? sp.x : INF, x1 = valid ? sp.x : -INF, y0 = valid ? sp.y : INF, y1 = valid ? sp.y : -INF;
+        row_box_dpp(x0, x1, y0, y1);
+        float4 b0 = make_float4(readlane_f(x0, 0), readlane_f(y0, 0), readlane_f(x1, 0), readlane_f(y1, 0));
+        float4 b1 = make_float4(readlane_f(x0, 16), readlane_f(y0, 16), readlane_f(x1, 16), readlane_f(y1, 16));
+        float4 b2 = make_float4(readlane_f(x0, 32), readlane_f(y0, 32), readlane_f(x1, 32), readlane_f(y1, 32));
+        float4 b3 = make_float4(readlane_f(x0, 48), readlane_f(y0, 48), readlane_f(x1, 48), readlane_f(y1, 48));
+        return [=, &pv](uint32_t idx, bool have) -> uint32_t {
+            const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
+            const Ellipse e = ellipse_of(A, B.x);
+            const float4 bx[4] = {b0, b1, b2, b3};
+            uint32_t gm = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (have && bx[g].x <= bx[g].z && ellipse_reaches_rect(e, bx[g].x, bx[g].y, bx[g].z, bx[g].w, pv.q_max)) gm |= 1u << g;
+            return gm;
+        };
+    };
     for_each_step<BWD_STEP>(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
         const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
         wave_lds_fence();
@@ -1323,7 +1392,7 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
 #pragma unroll
             for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], sum[q]);
         }
-    });
+    }, ranges_mask);
 }
 
 template <int C>
