@@ -3,18 +3,21 @@
 //
 // Samples build = 4 launches (bbox partials -> cell key + rank -> scan -> scatter); plan build =
 // the same chain for the Gaussians (sharing the launches of a samples build that runs with it) +
-// one launch that walks the Gaussian grid once per 64-point tile and writes the tile's list.  No
-// memset, no host synchronisation, static memory.
+// one launch in which every wave walks the Gaussian grid once for four consecutive 64-point tiles
+// and writes their lists (tile list with group masks for the backward, four group lists for the
+// forward).  No memset, no host synchronisation, static memory.
 // Sampling kernels: one wave = one tile of 64 consecutive sorted points (lane = point), one DPP row =
-// one 16-point group.  The wave reads its list 64 entries at a time, gathers their 32-byte records
-// into wave-private LDS, splits the entries by their group masks into four per-row index lists
-// (ballot + mbcnt) and evaluates them row-wise: in one instruction every row works on its OWN
-// Gaussian, read from LDS with a row-uniform address.  No workgroup barriers; HBM traffic is the
-// point stream (sorted points in, outputs out through the points' original indices) plus list and
-// record reads that mostly hit L2.
+// one 16-point group.  Forward: every row streams its own group list, gathers the 32-byte records
+// into its LDS queue and the rows are evaluated together -- in one instruction every row works on
+// its OWN Gaussian, read from LDS with a row-uniform address.  Backward: the tile list 64 entries at
+// a time, split by the group masks into four per-row lists (ballot + mbcnt), rows reduced by a
+// transposing DPP fold into an LDS table, one atomic per entry and value.  No workgroup barriers;
+// HBM traffic is the point stream (sorted points in, outputs out through the points' original
+// indices) plus list and record reads that mostly hit L2.
 //
 // Build-time knobs (defaults measured on MI355X): PIGS_FWD_WAVES, PIGS_FWD_UNROLL,
-// PIGS_BWD_WAVES, PIGS_TRAV_STEPS, PIGS_XCD_CHUNK.
+// PIGS_GROUP_CAP, PIGS_BWD_WAVES, PIGS_BWD_STEP, PIGS_BWD_SPREAD, PIGS_LISTS_TPW, PIGS_TRAV_STEPS,
+// PIGS_XCD_CHUNK.
 #include "pair_math.h"
 #include "plan.h"
 #include "launch.h"
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Sampling kernels.  One wave = one tile; a step = 64 list entries (lane = entry).
+// Sampling kernels.  One wave = one tile.
 // ------------------------------------------------------------------------------------------
 struct Rec {
     float mu[2], con[3], v[2];
@@ -894,14 +897,13 @@ __device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile,
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward.  Every group (DPP row) of the wave keeps its own queue of RECORDS in LDS: a step's
-// entries are appended to the queues of the groups in their masks (ballot + mbcnt give the
-// positions; a record is copied up to four times), each queue taking what it has room for; when
-// a queue is full -- or the list ends -- the queues are evaluated row-wise: in one instruction
-// every row works on its OWN Gaussian, read from LDS at an address that is affine in the loop
-// counter (no index indirection: the reads of the next rows are in flight while the current ones
-// are evaluated).  Queues shorter than the longest are padded with all-zero records (v = 0:
-// contributes nothing); on long lists every queue is full at every flush but the last.
+// Forward.  Every group (DPP row) of the wave keeps its own queue of RECORDS in LDS and fills it from
+// ITS OWN list (the group lists of the plan; 32 positions per chunk, two rounds of 16 gathers in
+// flight), the all-zero record behind the list's end (v = 0: contributes nothing); then the queues
+// are evaluated row-wise up to the longest list: in one instruction every row works on its OWN
+// Gaussian, read from LDS at an address that is affine in the loop counter (no index indirection:
+// the reads of the next rows are in flight while the current ones are evaluated).  A tile in
+// record-range mode fills the queues by testing the ranges' records against the group boxes.
 // A record in LDS is {mux, muy, a, b}, {c, v0, v1, -}: one ds_read_b128 + one ds_read_b64 (c = 1).
 // The reads are inline asm: hipcc fuses 8-byte LDS reads of neighbouring rows into ds_read2_b64,
 // which moves 16 bytes in 8 LDS cycles where ds_read_b128 takes 4 (MI355X_MICROARCH.md, LDS
