@@ -478,12 +478,14 @@ def test_plan_workspaces_are_recycled_only_after_their_plan_died(Sampler):
     assert kept[0].N == 300
 
 
-def test_sparse_scattered_points_keep_their_group_lists(Sampler):
+@pytest.mark.parametrize("N,mode", [(8000, "groups"), (20000, "ranges")])
+def test_sparse_scattered_points_keep_their_group_lists(Sampler, N, mode):
     """Points far apart from each other (the thin outskirts of a clustered cloud) share no Gaussians:
     a tile of 64 of them meets more than the tile list holds while its four group lists still fit.
-    Such tiles keep their group lists (forward) and the backward walks those; results as ever."""
+    Such tiles keep their group lists (forward) and the backward walks those.  With more Gaussians per
+    point even a group list overflows: those tiles fall back to record ranges, whose records the
+    sampling kernels test against the group boxes themselves.  Results as ever in both cases."""
     rng = np.random.default_rng(31)
-    N = 8000
     means, con, values = random_gaussians(rng, N, 1, log_sigma_mean=-4.6, log_sigma_std=0.2)
     core = rng.normal(0, 0.02, (60000, 2))                       # a dense core sets the cell size ...
     far = rng.uniform(-1, 1, (1500, 2))                          # ... and the rest is scattered thinly
@@ -491,7 +493,7 @@ def test_sparse_scattered_points_keep_their_group_lists(Sampler):
     s = check_case(Sampler, means, con, values, samples, orders=(0, 1, 2), tol=TOL, gtol=2e-5)
     from tools.prof_step import list_stats
     st = list_stats(s._plan)
-    assert st["groups_only_tiles"] > 0, st                       # the case is what it claims to be
+    assert st["groups_only_tiles" if mode == "groups" else "ranges_tiles"] > 0, st      # the case is what it claims to be
 
 
 def test_backward_tile_shuffle_with_a_partial_last_chunk(Sampler):
