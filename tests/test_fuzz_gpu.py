@@ -48,7 +48,7 @@ def make_case(rng):
     return means, values, con, pts
 
 
-SEEDS = int(os.environ.get("PIGS_FUZZ_SEEDS", "60"))     # a longer campaign: PIGS_FUZZ_SEEDS=20000 pytest ... (passes)
+SEEDS = int(os.environ.get("PIGS_FUZZ_SEEDS", "60"))     # a longer campaign: PIGS_FUZZ_SEEDS=20000 pytest ... (passes, 80 s)
 
 
 @pytest.mark.parametrize("seed", range(SEEDS))
@@ -94,5 +94,9 @@ def test_binned_matches_dense(Sampler, seed):
         under = max(under, term[o] / max(top, 1e-30))
     for k, (a, b) in enumerate(zip(grads["dense"], grads["binned"])):
         assert torch.isfinite(a).all() and torch.isfinite(b).all(), ("grad", k, seed)
-        # random-sign weights cancel in the gradient sums: fp32 accumulation-order noise only
-        assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()) * under + 1e-30, ("grad", k, seed)
+        # random-sign weights cancel in the gradient sums: fp32 accumulation-order noise only.  The bar is
+        # that of a self-comparison, not of parity: in the one seed of 20 000 that came nearest (13186: points
+        # 26 units from the origin, sigma ~ 0.01; the two paths 8.1e-5 apart in the means' gradient) BOTH
+        # paths are 2.8e-3 from the float64 result on the same float32 inputs (tools/fuzz_one.py 13186 --oracle):
+        # what separates them is the order of the additions, not the cut-off
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) * under + 1e-30, ("grad", k, seed)
