@@ -8,6 +8,7 @@
 //   out:  dense out0, out1, out2; binned out0, out1, out2; binned g_means, g_conics, g_values
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -71,7 +72,22 @@ int main(int argc, char** argv) {
     CHECK_PIGS(pigs_plan_build(ws, pb, sws, sb, PIGS_BUILD_PLAN_WS_CLEAN, N, M, c, q_max, d_means, d_conics, d_values, d_samples, stream));
     CHECK_PIGS(pigs_plan_forward(ws, pb, sws, sb, N, M, c, q_max, 0x7, b0, b1, b2, nullptr, stream));
     CHECK_PIGS(pigs_plan_backward(ws, pb, sws, sb, N, M, c, q_max, 0x7, d_g0, d_g1, d_g2, nullptr, gm, gc, gv, stream));
+    // the samples half on its own (pigs_samples_build), then a plan on top of it: the same forward results
+    void *sws2, *ws2;
+    float* b0_2;
+    CHECK_HIP(hipMalloc(&sws2, sb)); CHECK_HIP(hipMalloc(&ws2, pb)); CHECK_HIP(hipMalloc(&b0_2, M * c * 4));
+    CHECK_PIGS(pigs_samples_build(sws2, sb, M, d_samples, stream));
+    CHECK_PIGS(pigs_plan_build(ws2, pb, sws2, sb, 0, N, M, c, q_max, d_means, d_conics, d_values, nullptr, stream));
+    CHECK_PIGS(pigs_plan_forward(ws2, pb, sws2, sb, N, M, c, q_max, 0x1, b0_2, nullptr, nullptr, nullptr, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
+    {
+        std::vector<float> x(M * c), y(M * c);
+        CHECK_HIP(hipMemcpy(x.data(), b0, M * c * 4, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(y.data(), b0_2, M * c * 4, hipMemcpyDeviceToHost));
+        double worst = 0, top = 0;
+        for (size_t k = 0; k < x.size(); ++k) { worst = std::fmax(worst, std::fabs((double)x[k] - y[k])); top = std::fmax(top, std::fabs((double)x[k])); }
+        if (worst > 1e-6 * top) { std::fprintf(stderr, "samples_build + plan_build differ from the fused build: %g of %g\n", worst, top); return 5; }
+    }
     uint32_t err = 0;
     CHECK_HIP(hipMemcpy(&err, (char*)ws + pigs_plan_error_offset(), 4, hipMemcpyDeviceToHost));
     if (err) { std::fprintf(stderr, "plan build reported a scan time-out\n"); return 4; }
