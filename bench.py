@@ -151,6 +151,69 @@ def graph_replay(GaussianSampler, t, pts_d, backend, n):
     return out
 
 
+def small_record(GaussianSampler, dev, reps=200):
+    """The reference's own training sizes (main_pn.py:57,103: N ~ 1e3 Gaussians, 1 024 collocation points)
+    in the call pattern of Model.sample (model_pn.py:766-788): preprocess(samples) + sample_gaussians /
+    _derivative / _laplacian, preprocess(bc_samples) + sample_gaussians, then ONE backward of all four
+    outputs (incoming gradients supplied: the sampler's own share of the step).  At these sizes the GPU
+    work is a few launches of a few microseconds: the figure is the host's.  Eager through the native host
+    extension, eager through the ctypes host, and the same step replayed from a hipGraph."""
+    from pigs_amd import synthetic
+    gs = synthetic.lattice_gaussians(40, 40, 1.3, seed=1)
+    gen = torch.Generator().manual_seed(3)
+    out = {"gaussians": 1600, "points": 1024, "bc_points": 1024,
+           "pattern": "model_pn.py:766-788: 2 preprocess, orders 0-2 + boundary u, 1 backward (sampler only)"}
+
+    def make(host):
+        t = {k: v.float().to(dev) for k, v in gs.items()}
+        for k in ("means", "values", "conics"):
+            t[k].requires_grad_(True)
+        pts = (torch.rand((1024, 2), generator=gen) * 2 - 1).to(dev)
+        bc = (torch.rand((1024, 2), generator=gen) * 2 - 1).to(dev)
+        smp = GaussianSampler(False, host=host)
+        gouts = []
+
+        def step():
+            smp.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+            outs = [smp.sample_gaussians(), smp.sample_gaussians_derivative(), smp.sample_gaussians_laplacian()]
+            smp.preprocess(t["means"], t["values"], t["covariances"], t["conics"], bc)
+            outs.append(smp.sample_gaussians())
+            if not gouts:
+                gouts.extend(torch.randn_like(o) for o in outs)
+            return torch.autograd.grad(outs, (t["means"], t["values"], t["conics"]), grad_outputs=gouts)
+        return step
+
+    def timed(fn):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize(dev)
+        gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        gc.enable()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    for host in ("native", "ctypes"):
+        out[f"eager_{host}_ms_per_step"] = timed(make(host))
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step = make("native")
+        for _ in range(3):
+            step()
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        keep = step()
+    out["graph_replay_ms_per_step"] = timed(graph.replay)
+    del graph, keep
+    torch.cuda.current_stream(dev).wait_stream(side)
+    out["eager_over_replay"] = out["eager_native_ms_per_step"] / out["graph_replay_ms_per_step"]
+    return out
+
+
 def host_cores():
     """Cores this process may actually use: affinity, capped by the cgroup CPU quota and by the
     GPU box's per-GPU share (16)."""
@@ -436,7 +499,12 @@ def main():
                 fwd_bwd["hipgraph_replay"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     # ---------------- extras ----------------
-    two_streams = kappa13 = None
+    two_streams = kappa13 = small = None
+    if not a.no_extras and dist is None:
+        try:
+            small = small_record(GaussianSampler, dev)
+        except Exception as e:                # report, never lose the bench line over the extra figure
+            small = {"error": f"{type(e).__name__}: {e}"[:200]}
     if not a.no_extras:
         # the same steps dealt round-robin to two HIP streams (extra figure, not `value`: independent evaluation
         # steps -- frames of a roll-out -- can overlap the latency-bound plan build of one with the forward of another)
@@ -491,7 +559,7 @@ def main():
         "host_issue_ms_per_step": host_cold * 1e3,
         "preheat_ms": preheat_ms, "value_warm_plan": warm["value"], "warm_plan": warm,
         "roofline": roofline, "roofline_bwd": roofline_bwd, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
-        "kappa_1_3": kappa13,
+        "kappa_1_3": kappa13, "small": small, "host": sampler.host,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(gs, pts)

@@ -3,9 +3,9 @@
 Public surface:
     GaussianSampler         drop-in for ``diff_gaussian_sampling.GaussianSampler``
     covariances             fused ``build_covariances`` / ``build_full_covariances`` (gaussians.py:163-193)
-    build()                 compile the HIP library in-tree (hipcc, gfx950)
+    build()                 compile the HIP library (hipcc, gfx950) and the native host extension in-tree
 """
-from .build import build  # noqa: F401
+from .build import build_all as build  # noqa: F401  (libpigs_amd.so + the native host extension)
 
 
 def __getattr__(name):

@@ -1,9 +1,11 @@
-"""Build pigs_amd/libpigs_amd.so (the C-ABI library of include/pigs_amd.h) with hipcc for gfx950.
+"""Build pigs_amd/libpigs_amd.so (the C-ABI library of include/pigs_amd.h) with hipcc for gfx950,
+and pigs_amd/_pigs_host.so (the native host side of GaussianSampler: a torch C++ extension over
+that C ABI, csrc_host/pigs_host.cpp) with g++.
 
     python -m pigs_amd.build [--force] [--verbose]
 
-hipcc cross-compiles without a GPU, so this also runs in GPU-less containers.  The library is
-built in-tree (git-ignored) so that it travels with the source tree to the GPU box.
+hipcc cross-compiles without a GPU, so this also runs in GPU-less containers.  Both libraries are
+built in-tree (git-ignored) so that they travel with the source tree to the GPU box.
 """
 import glob
 import hashlib
@@ -90,6 +92,64 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# ---- the native host extension (torch C++ extension; no device code: plain g++) -----------------
+HOST_SRC = os.path.join(HERE, "csrc_host", "pigs_host.cpp")
+HOST_LIB = os.path.join(HERE, "_pigs_host.so")
+HOST_STAMP = HOST_LIB + ".srchash"
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+              "-DTORCH_EXTENSION_NAME=_pigs_host", "-DTORCH_API_INCLUDE_EXTENSION_H", "-w"]
+
+
+def host_source_hash():
+    import torch
+    h = hashlib.sha256((" ".join(HOST_FLAGS) + torch.__version__).encode())
+    for p in (HOST_SRC, os.path.join(HERE, "..", "include", "pigs_amd.h")):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def host_needs_build():
+    if not os.path.exists(HOST_LIB) or not os.path.exists(HOST_STAMP):
+        return True
+    return open(HOST_STAMP).read().strip() != host_source_hash()
+
+
+def build_host(force=False, verbose=False):
+    """Compile the native host extension against this interpreter's torch.  Needs libpigs_amd.so
+    (it links against the C ABI).  Returns the extension path."""
+    build(force=False, verbose=verbose)
+    if not force and not host_needs_build():
+        return HOST_LIB
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tdir = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_HOME") or ce.ROCM_HOME or "/opt/rocm"
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", f"-I{sysconfig.get_paths()['include']}"]
+    abi = f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"
+    tmp = f"{HOST_LIB}.{os.getpid()}.tmp"
+    cmd = ([os.environ.get("CXX", "g++")] + HOST_FLAGS + [abi] + inc + [HOST_SRC, "-o", tmp,
+           f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
+           f"-L{rocm}/lib", "-lamdhip64", f"-L{HERE}", "-lpigs_amd", "-Wl,-rpath,$ORIGIN"])
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("host extension build failed:\n" + proc.stdout)
+    os.replace(tmp, HOST_LIB)
+    with open(f"{HOST_STAMP}.{os.getpid()}.tmp", "w") as f:
+        f.write(host_source_hash())
+    os.replace(f"{HOST_STAMP}.{os.getpid()}.tmp", HOST_STAMP)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    build(force=force, verbose=verbose)
+    build_host(force=force, verbose=verbose)
+    return LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build_all(force="--force" in sys.argv, verbose=True)
     print(LIB)
+    print(HOST_LIB)

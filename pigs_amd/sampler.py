@@ -20,6 +20,8 @@ All arithmetic runs in the HIP library behind the C ABI of include/pigs_amd.h; t
 or PyTorch fallback -- CPU tensors are rejected.
 """
 import ctypes
+import os
+import threading
 
 import torch
 
@@ -129,26 +131,31 @@ class _PlanPool:
 
     def __init__(self):
         self.free = {}             # key -> [workspace, ...]; dict order = least recently given first
+        # plans die wherever their last reference is dropped -- the autograd engine's worker threads and
+        # the garbage collector included -- while the main thread may be inside take()
+        self.lock = threading.Lock()
 
     def take(self, key):
-        lst = self.free.get(key)
-        if not lst:
-            return None
-        ws = lst.pop()
-        if not lst:
-            del self.free[key]
-        return ws
+        with self.lock:
+            lst = self.free.get(key)
+            if not lst:
+                return None
+            ws = lst.pop()
+            if not lst:
+                self.free.pop(key, None)
+            return ws
 
     def give(self, key, workspace):
-        lst = self.free.pop(key, [])
-        if len(lst) < self.KEEP:
-            lst.append(workspace)
-        self.free[key] = lst       # most recently given last
-        while sum(len(v) for v in self.free.values()) > self.KEEP_TOTAL:
-            oldest = next(iter(self.free))
-            self.free[oldest].pop(0)
-            if not self.free[oldest]:
-                del self.free[oldest]
+        with self.lock:
+            lst = self.free.pop(key, [])
+            if len(lst) < self.KEEP:
+                lst.append(workspace)
+            self.free[key] = lst       # most recently given last
+            while sum(len(v) for v in self.free.values()) > self.KEEP_TOTAL:
+                oldest = next(iter(self.free))
+                self.free[oldest].pop(0)
+                if not self.free[oldest]:
+                    del self.free[oldest]
 
 
 class Plan:
@@ -157,14 +164,17 @@ class Plan:
     once built; autograd nodes keep a reference, so later ``preprocess`` calls never disturb a
     pending backward."""
 
-    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "_pool", "_pool_key")
+    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "_pool", "_pool_key", "build_stream",
+                 "other_stream_used")
 
     BUILD_SAMPLES, WS_CLEAN = 1, 2      # pigs_amd.h: PIGS_BUILD_SAMPLES, PIGS_BUILD_PLAN_WS_CLEAN
 
-    def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None, pool=None):
+    def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None, pool=None,
+                 recorded_only=False):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
         self._pool = None
+        self.other_stream_used = False
         key = (self.N, self.M, self.c)
         nbytes = _WORKSPACE_BYTES.get(key)
         if nbytes is None:
@@ -176,6 +186,7 @@ class Plan:
         self.samples = sample_plan
         with _on_device(means.device):
             stream = _stream(means.device)
+            self.build_stream = stream.value
             self._pool_key = (self.N, self.M, self.c, means.device, stream.value)
             self.workspace = pool.take(self._pool_key) if pool is not None else None
             flags = 0 if sample_plan.built else self.BUILD_SAMPLES
@@ -188,12 +199,19 @@ class Plan:
                                      flags, self.N, self.M, self.c, self.q_max,
                                      _ptr(means), _ptr(conics), _ptr(values), _ptr(samples), stream)
         _lib.check(rc, "pigs_plan_build")
-        sample_plan.built = True
+        # a build that was only RECORDED into a hipGraph has not run: nothing eager may rely on it
+        sample_plan.built = not recorded_only
         self._pool = pool            # only a workspace whose build was launched completely goes back
+
+    def note_stream(self, stream_value):
+        """A launch on another stream than the build's reads the workspace: stream order no longer
+        covers its reuse, so it does not go back to the pool."""
+        if stream_value != self.build_stream:
+            self.other_stream_used = True
 
     def __del__(self):
         try:
-            if self._pool is not None:
+            if self._pool is not None and not self.other_stream_used:
                 self._pool.give(self._pool_key, self.workspace)
         except Exception:            # interpreter shutdown: nothing to keep
             pass
@@ -224,6 +242,8 @@ def forward_raw(means, values, conics, samples, mask, plan=None):
         with _on_device(means.device):
             if plan is not None:
                 sws = plan.samples.workspace
+                if hasattr(plan, "note_stream"):
+                    plan.note_stream(_stream(means.device).value)
                 rc = lib.pigs_plan_forward(_ptr(plan.workspace), plan.workspace.numel(), _ptr(sws), sws.numel(),
                                            N, M, c, plan.q_max, mask,
                                            _ptr(outs[0]), _ptr(outs[1]), _ptr(_slot2(outs)), _ptr(outs[3]),
@@ -251,6 +271,8 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
         with _on_device(means.device):
             if plan is not None and M > 0:
                 sws = plan.samples.workspace
+                if hasattr(plan, "note_stream"):
+                    plan.note_stream(_stream(means.device).value)
                 rc = lib.pigs_plan_backward(_ptr(plan.workspace), plan.workspace.numel(), _ptr(sws), sws.numel(),
                                             N, M, c, plan.q_max, mask,
                                             _ptr(gouts[0]), _ptr(gouts[1]), _ptr(_slot2(gouts)),
@@ -313,6 +335,26 @@ class _SampleFunction(torch.autograd.Function):
         return g_means, g_values, g_conics, None, None, None, None
 
 
+_FUSE_CODES = {"auto": 0, "all": 1, "none": 2}
+_BACKEND_CODES = {"auto": 0, "dense": 1, "binned": 2}
+
+
+def _load_native_host():
+    """The native host extension (pigs_amd/_pigs_host.so, csrc_host/pigs_host.cpp); there is no silent
+    fallback to the ctypes host: a missing extension raises."""
+    _lib.load()
+    try:
+        from . import _pigs_host
+    except ImportError as e:
+        raise ImportError(
+            "pigs_amd/_pigs_host.so (the native host side of GaussianSampler) is missing or does not load: "
+            f"{e}.  Build it first (python -m pigs_amd.build), or ask for the ctypes host explicitly "
+            "(GaussianSampler(..., host='ctypes') / PIGS_AMD_HOST=ctypes).") from e
+    if _pigs_host.ABI_VERSION != _lib.ABI_VERSION:
+        raise ImportError(f"_pigs_host.so was built against ABI {_pigs_host.ABI_VERSION}, expected {_lib.ABI_VERSION}; rebuild")
+    return _pigs_host
+
+
 class GaussianSampler:
     """MI355X-native replacement of ``diff_gaussian_sampling.GaussianSampler``.
 
@@ -335,7 +377,9 @@ class GaussianSampler:
     of the plan is rebuilt -- the reference's roll-out binds new Gaussians to a fixed grid every
     step (main_pn.py:317-324), its training step alternates between the collocation points and
     the boundary points (model_pn.py:766-785).  ``True`` remembers the last 4 sample tensors, an
-    integer that many, ``False`` rebuilds everything every time.
+    integer that many, ``False`` rebuilds everything every time.  While a hipGraph is being captured
+    nothing is looked up or remembered: the capture records the samples build itself, so a replay
+    after an in-place update of the samples re-sorts them.
 
     ``unpinned_aggregate`` (extension, keyword only): ``preprocess_aggregate`` / ``aggregate_neighbors``
     follow this repository's own definition (the reference's is not visible: parity unpinned) and
@@ -346,6 +390,19 @@ class GaussianSampler:
     launch when the problem is small enough to be launch-bound (M <= 65536), otherwise only the
     order asked for; ``"all"`` / ``"none"`` force either behaviour.  :meth:`sample` is the
     explicit fused entry point.
+
+    ``host`` (extension, keyword only): ``"native"`` (default; environment override PIGS_AMD_HOST) keeps
+    the sampler's state and its autograd node in the C++ torch extension ``pigs_amd/_pigs_host.so``
+    (csrc_host/pigs_host.cpp) -- what the reference's own boundary is (a compiled torch extension,
+    model_pn.py:11); ``"ctypes"`` is the same logic in Python over ``ctypes`` (this file).  Both call
+    the same C ABI; neither has a CPU fallback.
+
+    Memory: the autograd node of a launch owns the tensors bound by ``preprocess`` and the plan (160 B
+    per sample point at N > 512), and keeps them until every output of that launch is gone -- not just
+    until the first backward (the reference's scripts come back to another output of the same launch
+    after a non-retaining backward, test_derivatives.py:214-215, 349-352); saved-tensor hooks
+    (``save_on_cpu``, checkpointing) do not see them.  Roll-outs that keep every step's outputs keep
+    every step's plan.
     """
 
     FUSE_AUTO_MAX_POINTS = 1 << 16
@@ -355,31 +412,57 @@ class GaussianSampler:
     _warned_aggregate = False
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
-                 reuse_samples=True, unpinned_aggregate=False):
+                 reuse_samples=True, unpinned_aggregate=False, host=None):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):
             raise ValueError("backend must be 'auto', 'dense' or 'binned'")
         if not q_max > 0:
             raise ValueError("q_max must be positive")
+        if host is None:
+            host = os.environ.get("PIGS_AMD_HOST") or "native"
+        if host not in ("native", "ctypes"):
+            raise ValueError("host must be 'native' or 'ctypes'")
         self.debug = bool(flag)
         self.fuse = fuse
         self.backend = backend
+        self.host = host
         self.q_max = float(q_max)
         self.q_max_order3 = float(q_max_order3) if q_max_order3 is not None else self.q_max + 8.0
         if self.q_max_order3 < self.q_max:
             raise ValueError("q_max_order3 must not be below q_max")
         self.reuse_samples = 4 if reuse_samples is True else max(0, int(reuse_samples))
         self.unpinned_aggregate = bool(unpinned_aggregate)
-        self._plan3 = None
-        self._inputs = None
-        self._plan = None
-        self._sample_plan = None
-        self._sample_plans = []          # most recently used first, at most ``reuse_samples``
+        self._neighbors = None
+        self._st_plan3 = None
+        self._st_inputs = None
+        self._st_plan = None
+        self._st_sample_plans = []       # most recently used first, at most ``reuse_samples``
         self._plan_pool = _PlanPool()
         self._samples_source = None
         self._cache = {}
         _lib.load()  # fail at construction, not at first use, if the HIP library is missing
+        self._core = None
+        if host == "native":
+            self._core = _load_native_host().SamplerCore(self.debug, _FUSE_CODES[fuse], _BACKEND_CODES[backend],
+                                                         self.q_max, self.q_max_order3, self.reuse_samples)
+
+    # state lives in the native core when there is one
+    @property
+    def _plan(self):
+        return self._core.plan if self._core is not None else self._st_plan
+
+    @property
+    def _plan3(self):
+        return self._core.plan3 if self._core is not None else self._st_plan3
+
+    @property
+    def _inputs(self):
+        return self._core.inputs() if self._core is not None else self._st_inputs
+
+    @property
+    def _sample_plans(self):
+        return self._core.sample_plans if self._core is not None else self._st_sample_plans
 
     # ------------------------------------------------------------------ preprocess
     def preprocess(self, means, values, covariances, conics, samples):
@@ -390,6 +473,13 @@ class GaussianSampler:
         ``covariances`` does not enter the sampled values (the reference's dense twin,
         gaussians.py:48-58, never reads it); it is accepted for interface parity.
         """
+        for name, t in (("means", means), ("values", values), ("conics", conics), ("samples", samples)):
+            if not isinstance(t, torch.Tensor):
+                raise TypeError(f"{name} must be a torch.Tensor")
+        if self._core is not None:
+            self._neighbors = None
+            self._core.preprocess(means, values, covariances, conics, samples)
+            return
         if means.dim() != 2:
             raise ValueError(f"means must be [N, d], got {tuple(means.shape)}")
         N, d = means.shape
@@ -397,8 +487,6 @@ class GaussianSampler:
             raise NotImplementedError(f"d = {d} is not supported (d in {{1, 2}})")
         nf = d * (d + 1) // 2
         for name, t in (("means", means), ("values", values), ("conics", conics), ("samples", samples)):
-            if not isinstance(t, torch.Tensor):
-                raise TypeError(f"{name} must be a torch.Tensor")
             if not t.is_cuda:
                 raise RuntimeError(f"{name} is on {t.device}: GaussianSampler runs on the GPU only "
                                    "(no CPU fallback)")
@@ -432,53 +520,59 @@ class GaussianSampler:
             warnings.warn("GaussianSampler: samples.requires_grad is set, but the sampler returns no gradient "
                           "with respect to the sample points (as the reference, whose tests ask for the gradients "
                           "of means, values and conics only); use the derivative outputs instead", stacklevel=2)
-        self._inputs = (means.contiguous(), values.contiguous(), conics.contiguous(),
-                        samples.detach().contiguous())
+        self._st_inputs = (means.contiguous(), values.contiguous(), conics.contiguous(),
+                           samples.detach().contiguous())
         self._samples_source = samples
         self._cache = {}
-        self._plan = None
-        self._plan3 = None
+        self._st_plan = None
+        self._st_plan3 = None
         self._neighbors = None
-        mc, vc, cc, sc = self._inputs
+        mc, vc, cc, sc = self._st_inputs
         use_plan = self.backend == "binned" or (
             self.backend == "auto" and N * sc.shape[0] >= self.BINNED_AUTO_MIN_PAIRS)
         if use_plan and Plan.supported(mc, vc, sc):
-            self._plan = self._build_plan(self.q_max)
+            self._st_plan = self._build_plan(self.q_max)
         elif self.backend == "binned" and N > 0 and sc.shape[0] > 0:
             raise NotImplementedError("backend='binned' needs float32, d = 2, c <= 2")
 
     def _build_plan(self, q_max, sample_plan=None):
         """A plan for the bound inputs; the samples half is reused when ``preprocess`` was handed an
-        unmodified samples tensor it remembers (``reuse_samples``)."""
-        mc, vc, cc, sc = self._inputs
-        sp = sample_plan or next((p for p in self._sample_plans if p.matches(self._samples_source)), None)
-        # memory handed out while a hipGraph is being captured belongs to the graph: it neither comes from
-        # the pool nor goes back to it
-        pool = None if torch.cuda.is_current_stream_capturing() else self._plan_pool
+        unmodified samples tensor it remembers (``reuse_samples``).  While a hipGraph is being captured
+        nothing is looked up and nothing is remembered: the capture has to record the samples build
+        itself (a replay after an in-place update of the static samples input must re-sort them), its
+        workspaces belong to the graph (they neither come from the pool nor go back to it), and a
+        SamplePlan that was only recorded has not been built as far as later eager calls go."""
+        mc, vc, cc, sc = self._st_inputs
+        capturing = torch.cuda.is_current_stream_capturing()
+        sp = sample_plan
+        if sp is None and not capturing:
+            sp = next((p for p in self._st_sample_plans if p.matches(self._samples_source)), None)
+        pool = None if capturing else self._plan_pool
         with torch.no_grad():
-            plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source, pool)
-        self._sample_plan = plan.samples
-        if self.reuse_samples:
-            self._sample_plans = [plan.samples] + [p for p in self._sample_plans if p is not plan.samples]
-            del self._sample_plans[self.reuse_samples:]
-        if self.debug:
+            plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source, pool,
+                        recorded_only=capturing)
+        if self.reuse_samples and not capturing:
+            self._st_sample_plans = [plan.samples] + [p for p in self._st_sample_plans if p is not plan.samples]
+            del self._st_sample_plans[self.reuse_samples:]
+        if self.debug and not capturing:
             torch.cuda.synchronize(mc.device)
             plan.check()
         return plan
 
     # ------------------------------------------------------------------ sampling
     def _require_inputs(self):
-        if self._inputs is None:
+        inputs = self._inputs
+        if inputs is None:
             raise RuntimeError("preprocess() must be called before sampling")
-        return self._inputs
+        return inputs
 
     def _plan_for(self, mask):
         """The plan a launch with this order mask runs on: third derivatives get the wider cut-off."""
-        if self._plan is None or not mask & 8 or self.q_max_order3 == self.q_max:
-            return self._plan
-        if self._plan3 is None:
-            self._plan3 = self._build_plan(self.q_max_order3, self._plan.samples)     # same points: the sorted samples are shared
-        return self._plan3
+        if self._st_plan is None or not mask & 8 or self.q_max_order3 == self.q_max:
+            return self._st_plan
+        if self._st_plan3 is None:
+            self._st_plan3 = self._build_plan(self.q_max_order3, self._st_plan.samples)     # same points: the sorted samples are shared
+        return self._st_plan3
 
     def _compute(self, mask):
         means, values, conics, samples = self._require_inputs()
@@ -487,6 +581,8 @@ class GaussianSampler:
             self._cache[k] = o
 
     def _get(self, order):
+        if self._core is not None:
+            return self._core.get(order)
         if order not in self._cache:
             means, _, _, samples = self._require_inputs()
             mask = 1 << order
@@ -505,6 +601,9 @@ class GaussianSampler:
         orders = tuple(TRACE if o == "lap" else int(o) for o in orders)
         if any(o < 0 or o > TRACE for o in orders):
             raise ValueError('orders must be in 0..3 or "lap"')
+        if self._core is not None:
+            return self._core.sample(list(orders))
+        self._require_inputs()
         want = set(o for o in orders if o not in self._cache)
         if TRACE in want and (2 in want or 2 in self._cache):
             want.discard(TRACE)                    # the Hessian is (being) computed: take its diagonal
@@ -563,6 +662,6 @@ class GaussianSampler:
         """[N, L] attention-weighted neighbour messages (model_pn.py:262-264); differentiable wrt all
         six arguments (test_neighbor_aggregation.py:89-98).  Parity unpinned: pigs_amd/aggregate.py."""
         from . import aggregate
-        if getattr(self, "_neighbors", None) is None:
+        if self._neighbors is None:
             raise RuntimeError("preprocess_aggregate() must be called before aggregate_neighbors()")
         return aggregate.aggregate(self._neighbors, features, transform, queries, keys, frequencies, distance_transform)
