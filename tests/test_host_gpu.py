@@ -50,11 +50,13 @@ def test_hosts_agree_forward_and_backward(hip_lib, backend):
         grads = torch.autograd.grad(loss, (t["means"], t["values"], t["conics"]))
         res[host] = [o.detach() for o in outs] + list(grads)
         assert (s._plan is not None) == (backend == "binned")
-    for a, b in zip(res["native"], res["ctypes"]):
-        if backend == "dense":
-            assert torch.equal(a, b)          # same kernels, same launch geometry: bit-identical
+    for k, (a, b) in enumerate(zip(res["native"], res["ctypes"])):
+        if backend == "dense" and k < 4:
+            assert torch.equal(a, b)          # same forward kernel, same launch geometry: bit-identical
         else:
-            assert rel(a, b) < 2e-6           # list order depends on the build's atomics: last-bit differences
+            # binned: list order depends on the build's atomics; dense backward: its cross-workgroup sums are
+            # atomics too -- last-bit differences between any two runs
+            assert rel(a, b) < 2e-6
     args = [t[k].detach().cpu().double().numpy() for k in ("means", "conics", "values")]
     exp = c_oracle.forward(*args, pts.cpu().double().numpy(), orders=(0, 1, 2, 3))
     for o in range(4):
