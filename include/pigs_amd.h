@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 5
+#define PIGS_ABI_VERSION 6
 
 enum pigs_status {
     PIGS_OK = 0,
@@ -125,9 +125,13 @@ int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, con
  *                            or the caller zero-filled it.  Saves the zeroing launch of a build on an
  *                            existing samples workspace (4 launches instead of 5); ignored together
  *                            with PIGS_BUILD_SAMPLES, whose first launch zeroes anyway.
- * (ABI 4 called this parameter build_samples: 0 / 1 keep their meaning.) */
+ * (ABI 4 called this parameter build_samples: 0 / 1 keep their meaning.)
+ *   PIGS_BUILD_DEBUG_NO_LOOKBACK  test hook: the in-kernel scans never use their workgroup-to-workgroup
+ *                            hand-over and take the recompute path everywhere (see pigs_*_error_offset);
+ *                            results are the same, the build is slower. */
 #define PIGS_BUILD_SAMPLES 1
 #define PIGS_BUILD_PLAN_WS_CLEAN 2
+#define PIGS_BUILD_DEBUG_NO_LOOKBACK 4
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
                     int flags, int64_t N, int64_t M, int c, float q_max,
                     const void* means, const void* conics, const void* values, const void* samples, void* stream);
@@ -141,10 +145,12 @@ int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samp
                        const void* gout0, const void* gout1, const void* gout2, const void* gout3,
                        void* g_means, void* g_conics, void* g_values, void* stream);
 
-/* Byte offset, inside a samples / plan workspace, of a uint32 that a build leaves at 0 and sets to
- * non-zero when its in-kernel scan gave up waiting for a predecessor workgroup (a result built
- * from such a workspace is invalid; never observed -- the wait is bounded so that a stuck
- * predecessor is an error instead of a hung device).  For debugging hosts to read back. */
+/* Byte offset, inside a samples / plan workspace, of a uint32 DIAGNOSTIC that a build leaves at 0 and
+ * sets to non-zero when a workgroup of its in-kernel scan did not receive a predecessor's total within
+ * the bounded wait and summed that predecessor's counters itself.  The result is valid either way
+ * (the counters are final before the scan starts); the flag only says that the slow path ran -- never
+ * observed with the hardware's in-order dispatch, always with PIGS_BUILD_DEBUG_NO_LOOKBACK.
+ * (ABI <= 5: the scan gave up instead and this word meant "workspace invalid".) */
 size_t pigs_samples_error_offset(void);
 size_t pigs_plan_error_offset(void);
 

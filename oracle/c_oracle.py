@@ -28,6 +28,7 @@ def lib():
         _lib.pigs_oracle_forward.argtypes = [ctypes.c_int] * 3 + [ctypes.c_long] * 2 + [_P] * 8
         _lib.pigs_oracle_backward.restype = ctypes.c_int
         _lib.pigs_oracle_backward.argtypes = [ctypes.c_int] * 3 + [ctypes.c_long] * 2 + [_P] * 11
+        _lib.pigs_oracle_backward_abs.argtypes = [ctypes.c_int] * 3 + [ctypes.c_long] * 2 + [_P] * 11
         _lib.pigs_oracle_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -70,8 +71,10 @@ def forward(means, conics_flat, values, samples, orders=(0, 1, 2)):
     return out
 
 
-def backward(means, conics_flat, values, samples, grads):
-    """Dense VJP in float64.  grads: {order: grad_output}.  Returns (g_means, g_conics_flat, g_values)."""
+def backward(means, conics_flat, values, samples, grads, absolute=False):
+    """Dense VJP in float64.  grads: {order: grad_output}.  Returns (g_means, g_conics_flat, g_values).
+    ``absolute``: every (sample, Gaussian) pair's contribution enters in absolute value -- the magnitude
+    float32 accumulation errors are measured against (see :func:`accumulation_bound`)."""
     means = np.asarray(means)
     N, d = means.shape
     means = _f64(means, (N, d))
@@ -86,8 +89,19 @@ def backward(means, conics_flat, values, samples, grads):
     gs = {o: _f64(g, sh[o]) for o, g in grads.items() if g is not None}
     mask = sum(1 << o for o in gs)
     gm, gc, gv = np.zeros_like(means), np.zeros_like(conics), np.zeros_like(values)
-    rc = lib().pigs_oracle_backward(d, c, mask, N, M, _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
-                                    *[_ptr(gs.get(o)) for o in range(4)], _ptr(gm), _ptr(gc), _ptr(gv))
+    fn = lib().pigs_oracle_backward_abs if absolute else lib().pigs_oracle_backward
+    rc = fn(d, c, mask, N, M, _ptr(means), _ptr(conics), _ptr(values), _ptr(samples),
+            *[_ptr(gs.get(o)) for o in range(4)], _ptr(gm), _ptr(gc), _ptr(gv))
     if rc:
         raise ValueError(f"pigs_oracle_backward: unsupported d={d} c={c}")
     return gm, gc, gv
+
+
+def accumulation_bound(means, conics_flat, values, samples, grads, ulps=1e-6, floor=1e-6):
+    """Per-entry error bound of a float32 backward against :func:`backward`: ``ulps`` (1e-6 = ~8 float32
+    ulp: per-pair arithmetic + the order of summation) of the sum of the ABSOLUTE per-pair contributions to
+    the entry, plus ``floor`` of the largest entry (what a cut-off at exp(-q_max/2) may drop; a tenth of
+    the 1e-5 bar).  Returns (want, bound): two triples (g_means, g_conics_flat, g_values)."""
+    want = backward(means, conics_flat, values, samples, grads)
+    mag = backward(means, conics_flat, values, samples, grads, absolute=True)
+    return want, tuple(ulps * a + floor * np.abs(w).max() for a, w in zip(mag, want))

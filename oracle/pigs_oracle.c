@@ -112,18 +112,18 @@ int pigs_oracle_forward(int d, int c, int orders_mask, long N, long M,
  * dL/dmu_l = sum_m g (A p_l - sum_i dA_i C_il)
  * dL/dC_kl = sum_m g (-A x_k x_l / 2 + dA_k x_l + E_kl)   (full matrix), folded to flat.
  */
-int pigs_oracle_backward(int d, int c, int orders_mask, long N, long M,
+static int backward_impl(int d, int c, int orders_mask, long N, long M,
                          const double *means, const double *conics, const double *values,
                          const double *samples,
                          const double *g0, const double *g1, const double *g2, const double *g3,
-                         double *g_means, double *g_conics, double *g_values) {
+                         double *g_means, double *g_conics, double *g_values, int abs_mode) {
     if (d < 1 || d > MAXD || c < 1 || c > MAXC) return 1;
     const int nf = d * (d + 1) / 2;
 #pragma omp parallel for schedule(dynamic, 4)
     for (long n = 0; n < N; ++n) {
         double C[MAXD][MAXD];
         unpack_conic(d, conics + n * nf, C);
-        double gm[MAXD] = {0}, gC[MAXD][MAXD] = {{0}}, gv[MAXC] = {0};
+        double gm[MAXD] = {0}, gF[MAXD * (MAXD + 1) / 2] = {0}, gv[MAXC] = {0};
         for (long m = 0; m < M; ++m) {
             double x[MAXD], p[MAXD], q = 0.0;
             for (int i = 0; i < d; ++i) x[i] = samples[m * d + i] - means[n * d + i];
@@ -166,26 +166,53 @@ int pigs_oracle_backward(int d, int c, int orders_mask, long N, long M,
                                 E[i][k] += v * G * p[j];
                                 E[j][k] += v * G * p[i];
                             }
-                gv[ch] += g * F;
+                gv[ch] += abs_mode ? fabs(g * F) : g * F;
                 A += v * F;
             }
             for (int l = 0; l < d; ++l) {
                 double t = A * p[l];
                 for (int i = 0; i < d; ++i) t -= dA[i] * C[i][l];
-                gm[l] += g * t;
+                gm[l] += abs_mode ? fabs(g * t) : g * t;
             }
+            /* this pair's contribution to the FLAT conic gradient [G00, G01 + G10, G11] */
+            double pc[MAXD][MAXD];
             for (int k = 0; k < d; ++k)
                 for (int l = 0; l < d; ++l)
-                    gC[k][l] += g * (-0.5 * A * x[k] * x[l] + dA[k] * x[l] + E[k][l]);
+                    pc[k][l] = g * (-0.5 * A * x[k] * x[l] + dA[k] * x[l] + E[k][l]);
+            int f = 0;
+            for (int i = 0; i < d; ++i)
+                for (int j = i; j < d; ++j) {
+                    const double t = (i == j) ? pc[i][i] : pc[i][j] + pc[j][i];
+                    gF[f++] += abs_mode ? fabs(t) : t;
+                }
         }
         for (int l = 0; l < d; ++l) g_means[n * d + l] = gm[l];
         for (int ch = 0; ch < c; ++ch) g_values[n * c + ch] = gv[ch];
-        int k = 0;
-        for (int i = 0; i < d; ++i)
-            for (int j = i; j < d; ++j) {
-                g_conics[n * nf + k] = (i == j) ? gC[i][i] : gC[i][j] + gC[j][i];
-                ++k;
-            }
+        for (int f = 0; f < nf; ++f) g_conics[n * nf + f] = gF[f];
     }
     return 0;
+}
+
+int pigs_oracle_backward(int d, int c, int orders_mask, long N, long M,
+                         const double *means, const double *conics, const double *values,
+                         const double *samples,
+                         const double *g0, const double *g1, const double *g2, const double *g3,
+                         double *g_means, double *g_conics, double *g_values) {
+    return backward_impl(d, c, orders_mask, N, M, means, conics, values, samples, g0, g1, g2, g3,
+                         g_means, g_conics, g_values, 0);
+}
+
+/*
+ * The same sums with every (sample, Gaussian) pair's contribution taken in ABSOLUTE value: the
+ * magnitude a float32 accumulation error is measured against (an entry that is a small difference
+ * of large contributions cannot be summed to 1e-5 of ITSELF in float32 by any order of summation;
+ * tests bound the error of each entry by a few ulp of this sum).  Test infrastructure only.
+ */
+int pigs_oracle_backward_abs(int d, int c, int orders_mask, long N, long M,
+                             const double *means, const double *conics, const double *values,
+                             const double *samples,
+                             const double *g0, const double *g1, const double *g2, const double *g3,
+                             double *g_means, double *g_conics, double *g_values) {
+    return backward_impl(d, c, orders_mask, N, M, means, conics, values, samples, g0, g1, g2, g3,
+                         g_means, g_conics, g_values, 1);
 }

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIGS_AMD_LIB") or os.path.join(HERE, "libpigs_amd.so")
 
 PIGS_F32, PIGS_F64 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -4,7 +4,7 @@
 // GPU and the path taken for small problems (the PINN training loops call the sampler with
 // N ~ 1e3 Gaussians x M ~ 1e3 points: model_pn.py:768-772, test_no_mlp.py:104-125) and for
 // float64 (gradcheck, test_derivatives.py:96-106).  Large N x M goes through the binned path
-// (binned.hip).
+// (plan.hip).
 //
 // Forward:  lane = sample point, Gaussian parameters are wave-uniform and arrive through the
 //           scalar data path (s_load) -- no LDS or VGPR traffic per Gaussian.  The NW waves of

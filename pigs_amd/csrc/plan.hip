@@ -100,6 +100,7 @@ struct BuildArgs {
     float q_max;
     // which halves this build covers
     int do_samples, do_plan;
+    int no_lookback;      // test hook: the scan's workgroups never publish; every look-back recomputes
 };
 
 __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
@@ -300,10 +301,13 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
 // PLAN_SCAN_BLOCK counters (one coalesced uint4 per thread), publishes its total as one 8-byte
 // {flag, total} granule (single agent-scope store: data and flag travel together, no fence
 // needed) and sums the granules of the workgroups before it; nobody waits on a later workgroup.
-// The wait on a predecessor is bounded: in-order dispatch (what the hardware does) makes it
-// short, and should a predecessor ever fail to arrive the kernel ends with `scan_error` set in
-// the workspace header instead of hanging the device.
-constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 22;
+// The wait on a predecessor is bounded, and a predecessor that has not published within the bound is
+// not an error: the counters are final before this launch starts (the count kernel has completed),
+// so the waiting thread sums that workgroup's PLAN_SCAN_BLOCK counters ITSELF -- slower, never
+// wrong, whatever order the hardware dispatches workgroups in.  `scan_error` in the workspace header
+// only records that this happened (a diagnostic; never seen with in-order dispatch).
+// `no_lookback` (PIGS_BUILD_DEBUG_NO_LOOKBACK) makes every thread take that path: the test hook.
+constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 14;
 __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     __shared__ uint32_t sh[4];
     __shared__ uint32_t sh2[4];
@@ -326,20 +330,29 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     }
     if (lane == 63) sh[wave] = inc;
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && !a.no_lookback)
         __hip_atomic_store(&agg[b], (1ull << 32) | (sh[0] + sh[1] + sh[2] + sh[3]), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     uint32_t pre = 0;
     for (uint32_t t = threadIdx.x; t < b; t += 256) {
-        unsigned long long x;
-        uint32_t spins = 0;
-        do {
-            x = __hip_atomic_load(&agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!(x >> 32)) {
+        unsigned long long x = 0;
+        if (!a.no_lookback) {
+            for (uint32_t spins = 0; spins < SCAN_SPIN_LIMIT; ++spins) {
+                x = __hip_atomic_load(&agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x >> 32) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > SCAN_SPIN_LIMIT) { atomicOr(err, 1u); break; }
             }
-        } while (!(x >> 32));
+        }
+        if (!(x >> 32)) {       // not published (in time): workgroup t's total from its counters
+            const uint4* c4 = (const uint4*)counts + (size_t)t * 256;
+            uint32_t tot = 0;
+            for (int i = 0; i < 256; ++i) {
+                const uint4 w = c4[i];
+                tot += w.x + w.y + w.z + w.w;
+            }
+            x = tot;
+            atomicOr(err, 1u);
+        }
         pre += (uint32_t)x;
     }
 #pragma unroll
@@ -1308,9 +1321,11 @@ __device__ __forceinline__ uint32_t spread_tile(uint32_t t, uint32_t ntiles) {
 }
 
 template <int C, int MASK>
-constexpr int bwd_waves() {      // the widest gradient sets get 3 waves (168 VGPRs): no spills
-    return ((C == 2 && (MASK == 7 || MASK == 8 || MASK == 15)) || (C == 1 && MASK == 15)) ? 3
-           : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1 || MASK == 2)) ? PIGS_BWD_WAVES : 4;
+constexpr int bwd_waves() {
+    // c = 2: the sums table has 8 floats per row (NV = 7), 47.7 KB of LDS per workgroup -> 3 workgroups per
+    // CU whatever the registers allow, so every c = 2 variant asks for 3 waves (168 VGPRs: no spills in
+    // the widest gradient sets either); c = 1 with order 3 the same for its registers
+    return (C == 2 || MASK == 15) ? 3 : (MASK == 7 || MASK == 19 || MASK == 1 || MASK == 2) ? PIGS_BWD_WAVES : 4;
 }
 template <int C, int MASK>
 __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
@@ -1527,14 +1542,14 @@ static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_
 
 // The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
 // (build_plan) or both in the same four launches, then the tile lists.
-static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
+static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_lookback, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
                      int64_t M, int c, float q_max, const void* means, const void* conics, const void* values,
                      const void* samples, hipStream_t stream) {
     if (!samples_supported(M)) return PIGS_ERR_UNSUPPORTED;
     const SamplesLayout s = make_samples_layout(M);
     if (!sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
     BuildArgs a{};
-    a.do_samples = do_samples; a.do_plan = do_plan;
+    a.do_samples = do_samples; a.do_plan = do_plan; a.no_lookback = no_lookback;
     fill_samples_args(a, s, sws, samples);
     PlanLayout p{};
     if (do_plan) {
@@ -1567,13 +1582,13 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, void* sw
 }
 
 int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream) {
-    return run_build(true, false, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, nullptr, nullptr, nullptr, samples, stream);
+    return run_build(true, false, false, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, nullptr, nullptr, nullptr, samples, stream);
 }
 
 int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags, int64_t N, int64_t M, int c,
                float q_max, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream) {
-    return run_build((flags & 1) != 0, true, (flags & 2) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, means, conics, values,
+    return run_build((flags & 1) != 0, true, (flags & 2) != 0, (flags & 4) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, means, conics, values,
                      samples, stream);
 }
 

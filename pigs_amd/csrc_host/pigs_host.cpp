@@ -543,9 +543,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("version", &SamplePlan::version)
         .def_readonly("built", &SamplePlan::built)
         .def("matches", &SamplePlan::matches)
-        .def("check", [](const SamplePlan& s) {
-            if (error_flag(s.workspace, pigs_samples_error_offset()))
-                throw PigsFailure("samples build: the cell scan reported an error");
+        .def("scan_took_slow_path", [](const SamplePlan& s) {      // diagnostic (synchronises): include/pigs_amd.h
+            return error_flag(s.workspace, pigs_samples_error_offset()) != 0;
         });
     py::class_<Plan, std::shared_ptr<Plan>>(m, "Plan")
         .def_readonly("workspace", &Plan::workspace)
@@ -555,10 +554,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("c", &Plan::c)
         .def_readonly("q_max", &Plan::q_max)
         .def_readonly("other_stream_used", &Plan::other_stream_used)
-        .def("check", [](const Plan& p) {
-            if (error_flag(p.samples->workspace, pigs_samples_error_offset()))
-                throw PigsFailure("samples build: the cell scan reported an error");
-            if (error_flag(p.workspace, pigs_plan_error_offset())) throw PigsFailure("plan build: the cell scan reported an error");
+        .def("scan_took_slow_path", [](const Plan& p) {
+            return error_flag(p.samples->workspace, pigs_samples_error_offset()) != 0 ||
+                   error_flag(p.workspace, pigs_plan_error_offset()) != 0;
         });
     py::class_<Core>(m, "SamplerCore")
         .def(py::init<bool, int, int, double, double, int>(), py::arg("debug"), py::arg("fuse"), py::arg("backend"),

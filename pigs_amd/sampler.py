@@ -114,9 +114,10 @@ class SamplePlan:
             and source.stride() == self.source.stride() and source.dtype == self.source.dtype
             and source.device == self.source.device)) and source._version == self.version
 
-    def check(self):
-        if _error_flag(self.workspace, _lib.load().pigs_samples_error_offset()):
-            raise _lib.PigsError("samples build: the cell scan timed out waiting for a predecessor workgroup")
+    def scan_took_slow_path(self):
+        """Diagnostic (synchronises): a workgroup of the build's scan recomputed a predecessor's total
+        itself instead of receiving it (include/pigs_amd.h: the result is valid either way)."""
+        return bool(_error_flag(self.workspace, _lib.load().pigs_samples_error_offset()))
 
 
 class _PlanPool:
@@ -216,10 +217,10 @@ class Plan:
         except Exception:            # interpreter shutdown: nothing to keep
             pass
 
-    def check(self):
-        self.samples.check()
-        if _error_flag(self.workspace, _lib.load().pigs_plan_error_offset()):
-            raise _lib.PigsError("plan build: the cell scan timed out waiting for a predecessor workgroup")
+    def scan_took_slow_path(self):
+        """Diagnostic (synchronises): see :meth:`SamplePlan.scan_took_slow_path`."""
+        return self.samples.scan_took_slow_path() or bool(
+            _error_flag(self.workspace, _lib.load().pigs_plan_error_offset()))
 
     @staticmethod
     def supported(means, values, samples):
@@ -556,7 +557,6 @@ class GaussianSampler:
             del self._st_sample_plans[self.reuse_samples:]
         if self.debug and not capturing:
             torch.cuda.synchronize(mc.device)
-            plan.check()
         return plan
 
     # ------------------------------------------------------------------ sampling

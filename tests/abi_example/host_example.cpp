@@ -90,7 +90,8 @@ int main(int argc, char** argv) {
     }
     uint32_t err = 0;
     CHECK_HIP(hipMemcpy(&err, (char*)ws + pigs_plan_error_offset(), 4, hipMemcpyDeviceToHost));
-    if (err) { std::fprintf(stderr, "plan build reported a scan time-out\n"); return 4; }
+    // a diagnostic since ABI 6 (the scan recomputes what it does not receive in time; the result is valid)
+    if (err) std::fprintf(stderr, "note: the plan build's scan took its recompute path\n");
 
     std::FILE* g = std::fopen(argv[2], "wb");
     if (!g) return 1;

@@ -28,3 +28,23 @@ def hip_lib():
     pigs_amd.build()
     from pigs_amd import _lib
     return _lib.load()
+
+
+def grads_within_accumulation_bound(got, args, grads, ulps=1e-6, floor=1e-6):
+    """The gradient bar that replaces a loosened global tolerance: every entry of the float32 gradients
+    ``got`` = (g_means, g_conics_flat, g_values) must lie within ``ulps`` (1e-6 = ~8 float32 ulp) of the sum of
+    the ABSOLUTE per-pair contributions to that entry plus ``floor`` of the largest entry (what the cut-off
+    may drop), both from the float64 oracle on ``args`` = (means, conics_flat, values, samples) and the
+    incoming gradients ``grads`` = {order: array}.  An entry that is a small difference of large
+    contributions cannot be summed to 1e-5 of itself in float32 in any order; this is the bar a float32
+    dense sum can meet.  Returns [(name, worst error / bound)] of the entries that exceed it."""
+    import numpy as np
+    from oracle import c_oracle
+    want, bound = c_oracle.accumulation_bound(*args, grads, ulps=ulps, floor=floor)
+    bad = []
+    for name, g, w, b in zip(("means", "conics", "values"), got, want, bound):
+        g = g.detach().cpu().double().numpy() if hasattr(g, "detach") else np.asarray(g, dtype=np.float64)
+        ratio = np.abs(g.reshape(w.shape) - w) / b
+        if not (ratio <= 1.0).all():
+            bad.append((name, float(ratio.max())))
+    return bad

@@ -8,6 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import grads_within_accumulation_bound
 from oracle import c_oracle
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +54,7 @@ def test_cpp_host_links_and_matches_oracle(hip_lib, tmp_path):
     for k in range(3):
         assert rel(parts[k], exp[k].ravel()) < 1e-5, ("dense", k)
         assert rel(parts[3 + k], exp[k].ravel()) < 1e-5, ("binned", k)
-    gm, gc, gv = c_oracle.backward(*args, {k: f32[4 + k].astype(np.float64) for k in range(3)})
-    assert rel(parts[6], gm.ravel()) < 2e-5
-    assert rel(parts[7], gc.ravel()) < 2e-5
-    assert rel(parts[8], gv.ravel()) < 2e-5
+    # gradients: per entry within a few ulp of the sum of the absolute contributions (conftest.py)
+    bad = grads_within_accumulation_bound((parts[6], parts[7], parts[8]), args,
+                                          {k: f32[4 + k].astype(np.float64) for k in range(3)})
+    assert not bad, bad

@@ -100,3 +100,65 @@ def test_binned_matches_dense(Sampler, seed):
         # paths are 2.8e-3 from the float64 result on the same float32 inputs (tools/fuzz_one.py 13186 --oracle):
         # what separates them is the order of the additions, not the cut-off
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) * under + 1e-30, ("grad", k, seed)
+
+
+@pytest.mark.parametrize("k", [11, 30, 31])
+def test_fuzz_big_worst_cases_against_the_oracle(hip_lib, k):
+    """tools/fuzz_big.py (32 cases, seed 1) found binned and dense HIP gradients up to 2.2e-5 of the largest
+    entry apart at N ~ 3-19 k, M ~ 150-250 k (cases 31: 2.19e-5, 11: 1.74e-5, 30: 1.45e-5) -- a
+    self-comparison that names no culprit.  Here BOTH paths meet the float64 oracle: outputs on the points
+    where the two differ most plus a random slice (1e-5 of the largest output), gradients on the Gaussians
+    where the two differ most plus a random slice, every entry under the float32 accumulation bound (a few
+    ulp of the sum of the absolute per-pair contributions: tests/conftest.py).  The oracle's gradient of a
+    Gaussian needs that Gaussian and all the points only, so a subset of Gaussians is exact."""
+    import torch
+    from conftest import grads_within_accumulation_bound
+    from diff_gaussian_sampling import GaussianSampler
+    from oracle import c_oracle
+    from tools.fuzz_big import gen_cases
+    _, kind, means, con, values, pts, orders = next(cs for cs in gen_cases(32, 1) if cs[0] == k)
+    N, M, c = means.shape[0], pts.shape[0], values.shape[1]
+    rng = np.random.default_rng(100 + k)
+    f32 = [a.astype(np.float32) for a in (means, values, con, pts)]
+    shapes = {0: (M, c), 1: (M, 2, c), 2: (M, 2, 2, c), "lap": (M, c)}
+    rs = {o: rng.uniform(0, 1, shapes[o]).astype(np.float32) for o in orders}      # positive weights, as the tool's
+    res = {}
+    for backend in ("dense", "binned"):
+        t = [torch.tensor(a, device="cuda") for a in f32]
+        for x in t[:3]:
+            x.requires_grad_(True)
+        smp = GaussianSampler(False, backend=backend)
+        smp.preprocess(t[0], t[1], None, t[2], t[3])
+        outs = smp.sample(orders)
+        loss = sum((o * torch.tensor(rs[n], device="cuda")).sum() for n, o in zip(orders, outs))
+        loss.backward()
+        res[backend] = ([o.detach().cpu().double().numpy() for o in outs],
+                        [t[0].grad.cpu().double().numpy(), t[2].grad.cpu().double().numpy(), t[1].grad.cpu().double().numpy()])
+    a64 = [a.astype(np.float64) for a in (f32[0], f32[2], f32[1], f32[3])]          # means, conics, values, samples
+    # ---- outputs
+    diff = sum(np.abs(a - b).reshape(M, -1).max(1) / np.abs(a).max() for a, b in zip(res["dense"][0], res["binned"][0]))
+    psel = np.unique(np.concatenate((np.argsort(diff)[-512:], rng.choice(M, 1536, replace=False))))
+    exp = c_oracle.forward(a64[0], a64[1], a64[2], a64[3][psel], orders=(0, 1, 2))
+    for backend in ("dense", "binned"):
+        for n, o in zip(orders, res[backend][0]):
+            e = exp[2][:, 0, 0] + exp[2][:, 1, 1] if n == "lap" else exp[n]
+            scale = np.abs(o).max()
+            assert np.abs(o[psel] - e).max() / scale < 1e-5, (backend, n, np.abs(o[psel] - e).max() / scale)
+    # ---- gradients
+    gdiff = sum(np.abs(a - b).reshape(N, -1).max(1) / np.abs(a).max() for a, b in zip(res["dense"][1], res["binned"][1]))
+    gsel = np.unique(np.concatenate((np.argsort(gdiff)[-384:], rng.choice(N, min(N, 640), replace=False))))
+    g64 = {}
+    for n in orders:
+        if n == "lap":
+            g2 = np.zeros((M, 2, 2, c))
+            g2[:, 0, 0] = rs[n]; g2[:, 1, 1] = rs[n]
+            g64[2] = g2
+        else:
+            g64[n] = rs[n].astype(np.float64)
+    sub = (a64[0][gsel], a64[1][gsel], a64[2][gsel], a64[3])
+    floor_scale = [np.abs(g).max() for g in res["dense"][1]]
+    want, bound = c_oracle.accumulation_bound(*sub, g64, ulps=1e-6, floor=0.0)
+    for backend in ("dense", "binned"):
+        for name, g, w, b, fs in zip(("means", "conics", "values"), res[backend][1], want, bound, floor_scale):
+            ratio = np.abs(g[gsel] - w) / (b + 1e-6 * fs)
+            assert ratio.max() <= 1.0, (backend, name, float(ratio.max()), float((np.abs(g[gsel] - w) / fs).max()))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, golden_files
+from conftest import GOLDEN, golden_files, grads_within_accumulation_bound
 from oracle import c_oracle
 
 pytestmark = pytest.mark.gpu
@@ -70,12 +70,22 @@ def test_forward_f64_matches_reference(Sampler, name, fuse):
         assert rel(out, z[f"out{o}_f64"]) < F64_TOL, (name, o)
 
 
+def backends_for(name):
+    """The reference-generated fixtures run through the dense path (what "auto" picks at their sizes) and,
+    where the binned path takes the case (float32, d = 2, c <= 2), through it as well."""
+    return ["auto", "binned"] if "d2" in name or name in ("ref_test_derivatives.npz", "ref_test_gaussian_sampling.npz") else ["auto"]
+
+
+F32_CASES = [(n, b) for n in D12 for b in backends_for(n)]
+
+
 @pytest.mark.parametrize("fuse", ["none", "all"])
-@pytest.mark.parametrize("name", D12)
-def test_forward_f32_matches_reference(Sampler, name, fuse):
+@pytest.mark.parametrize("name,backend", F32_CASES)
+def test_forward_f32_matches_reference(Sampler, name, backend, fuse):
     z, t = load_case(name, torch.float32)
-    s = Sampler(True, fuse=fuse)
+    s = Sampler(True, fuse=fuse, backend=backend)
     s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+    assert (s._plan is not None) == (backend == "binned")
     outs = (s.sample_gaussians(), s.sample_gaussians_derivative(), s.sample_gaussians_laplacian(),
             s.sample_gaussians_third_derivative())
     # expected: float64 oracle on the float32-rounded inputs (isolates the kernel's arithmetic) ...
@@ -90,15 +100,16 @@ def test_forward_f32_matches_reference(Sampler, name, fuse):
         assert rel(out, z[f"out{o}_f64"]) < F32_TOL + input_rounding(exp[o], z[f"out{o}_f64"]), (name, o)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, F64_TOL), (torch.float32, F32_TOL)])
-@pytest.mark.parametrize("name", D12)
-def test_backward_per_order_matches_reference_autograd(Sampler, name, dtype, tol):
+@pytest.mark.parametrize("name,backend,dtype,tol",
+                         [(n, "auto", torch.float64, F64_TOL) for n in D12] + [(n, b, torch.float32, F32_TOL) for n, b in F32_CASES])
+def test_backward_per_order_matches_reference_autograd(Sampler, name, backend, dtype, tol):
     """test_derivatives.py:123,214-215,349-352: grads of each output wrt (means, values, conics)."""
     z, t = load_case(name, dtype)
     for k in ("means", "values", "conics"):
         t[k].requires_grad_(True)
-    s = Sampler(True, fuse="none")
+    s = Sampler(True, fuse="none", backend=backend)
     s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], t["samples"])
+    assert (s._plan is not None) == (backend == "binned")
     getters = (s.sample_gaussians, s.sample_gaussians_derivative, s.sample_gaussians_laplacian,
                s.sample_gaussians_third_derivative)
     for o, get in enumerate(getters):
@@ -270,12 +281,12 @@ def test_reference_autograd_call_patterns(Sampler, backend):
         shape = {0: (M, 1), 1: (M, 2, 1), 2: (M, 2, 2, 1)}[order]
         r = np.zeros(shape)
         r[(slice(None),) + comp] = 1.0
-        gm, gc, gv = c_oracle.backward(*args, {order: r})
-        return gm, gv, gc
+        return {order: r}
 
-    def check(got, exp, what):
-        for g, e, name in zip(got, exp, ("means", "values", "conics")):
-            assert rel(g, e) < 3e-5, (what, name, rel(g, e))
+    def check(got, grads, what):
+        # per entry: a few ulp of the sum of the absolute contributions (conftest.py); got = (means, values, conics)
+        bad = grads_within_accumulation_bound((got[0], got[2], got[1]), args, grads)
+        assert not bad, (what, bad)
 
     u = smp.sample_gaussians()
     check(torch.autograd.grad(u.sum(), t[:3], retain_graph=True, create_graph=True), expect(0, ()), "order 0")
