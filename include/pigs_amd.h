@@ -105,9 +105,16 @@ int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, c
  *
  * The sampling entry points evaluate, for every point, only the Gaussians whose q <= q_max ellipse
  * reaches the bounding box of the point's group (dropped terms are below exp(-q_max/2) of a term's
- * scale; q_max = 36 -> 1.5e-8).  The same (N, M, c, q_max) and the same samples workspace must be
- * passed to every call on a plan workspace.  pigs_plan_backward uses scratch inside the plan
- * workspace: calls sharing one must be stream ordered.
+ * scale; q_max = 36 -> 1.5e-8).  A plan holds TWO cut-offs (ABI 6): `q_max` for the forward and for
+ * the backward of gradients that arrive at orders 0 and 1, and `q_max_backward` >= q_max for the
+ * backward of gradients that arrive at order 2, order 3 or the trace (a value <= q_max, 0 included,
+ * means one cut-off).  Why: the conic gradient of a second-derivative term carries a q^2 prefactor and
+ * its sum over the points nearly cancels, so with thousands of points per Gaussian and one-signed
+ * incoming gradients the tail beyond q = 36 was 2.4e-5 of the largest entry; at 44 it is 1e-6
+ * (DESIGN.md "Cut-off").  The same (N, M, c) and the same samples workspace must be passed to every
+ * call on a plan workspace; the plan remembers its cut-offs (the q_max argument of pigs_plan_forward /
+ * pigs_plan_backward is kept for ABI shape and ignored since ABI 6).  pigs_plan_backward uses scratch
+ * inside the plan workspace: calls sharing one must be stream ordered.
  */
 size_t pigs_samples_workspace_bytes(int64_t M);                  /* 0 = unsupported size */
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsupported sizes */
@@ -133,7 +140,7 @@ int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, con
 #define PIGS_BUILD_PLAN_WS_CLEAN 2
 #define PIGS_BUILD_DEBUG_NO_LOOKBACK 4
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
-                    int flags, int64_t N, int64_t M, int c, float q_max,
+                    int flags, int64_t N, int64_t M, int c, float q_max, float q_max_backward,
                     const void* means, const void* conics, const void* values, const void* samples, void* stream);
 
 int pigs_plan_forward(void* workspace, size_t workspace_bytes, const void* samples_ws, size_t samples_ws_bytes,
@@ -157,11 +164,11 @@ size_t pigs_plan_error_offset(void);
 /* Introspection for tools and tests (never needed to use a plan): where the tile lists sit inside a
  * plan workspace.  info[0] = tiles, info[1] = entries per list slab, info[2] = byte offset of the
  * tile headers (8 uint32 each: [0] = count | mode << 30; mode 0 = list of `count` entries `sorted
- * Gaussian index | group mask << 28`, mode 1 = `count` record ranges {first, length}; [1..4] = the
- * lengths of the four group lists), info[3] = byte offset of the tile-list slabs (uint32[tiles][slab]),
+ * Gaussian index | wide group mask << 24 | narrow group mask << 28`, mode 1 = `count` record ranges
+ * {first, length}, mode 2 = group lists only; [1..4] = the lengths of the four group lists), info[3] = byte offset of the tile-list slabs (uint32[tiles][slab]),
  * info[4] = byte offset of the sorted -> caller Gaussian index table (uint32[N]), info[5] = byte
  * offset of the group-list slabs (uint32[tiles][4][slab], sorted Gaussian indices).
- * Returns PIGS_ERR_UNSUPPORTED for sizes the binned path does not take. */
+ * Returns PIGS_ERR_UNSUPPORTED for sizes the binned path does not take (N >= 2^24 among them). */
 int pigs_plan_layout_info(int64_t N, int64_t M, int c, int64_t info[6]);
 
 /*

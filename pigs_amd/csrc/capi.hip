@@ -100,11 +100,11 @@ int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, con
 }
 
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
-                    int flags, int64_t N, int64_t M, int c, float q_max, const void* means,
+                    int flags, int64_t N, int64_t M, int c, float q_max, float q_max_backward, const void* means,
                     const void* conics, const void* values, const void* samples, void* stream) {
     if (N < 0 || M < 0 || c < 1) return PIGS_ERR_INVALID;
     if (!means || !conics || !values || ((flags & PIGS_BUILD_SAMPLES) && !samples)) return PIGS_ERR_INVALID;
-    return plan_build(workspace, workspace_bytes, samples_ws, samples_ws_bytes, flags, N, M, c, q_max, means,
+    return plan_build(workspace, workspace_bytes, samples_ws, samples_ws_bytes, flags, N, M, c, q_max, q_max_backward, means,
                       conics, values, samples, (hipStream_t)stream);
 }
 

@@ -45,7 +45,7 @@ size_t samples_workspace_bytes(int64_t M);
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c);
 int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream);
 int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags, int64_t N, int64_t M, int c,
-               float q_max, const void* means, const void* conics, const void* values, const void* samples,
+               float q_max, float q_max_backward, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream);
 int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
                  float q_max, int mask, void* const* out, hipStream_t stream);

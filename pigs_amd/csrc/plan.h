@@ -24,8 +24,8 @@
 //      Gaussians whose ellipse can reach a rectangle" is a handful of CONTIGUOUS ranges of packed
 //      32-byte records: the cells within one cell of the rectangle, per level.
 //    * per TILE the list of Gaussians whose ellipse reaches the bounding box of the tile's points
-//      (exact ellipse / rectangle test), each entry carrying a 4-bit mask of the tile's GROUPS
-//      whose own box it reaches: entry = sorted index | mask << 28 (read by the backward); and per
+//      (exact ellipse / rectangle test), each entry carrying two 4-bit masks of the tile's GROUPS
+//      whose own box it reaches (wide / narrow cut-off, see LIST_IDX_BITS; read by the backward); and per
 //      GROUP the same Gaussians split by that mask into four packed index lists (read by the
 //      forward: every DPP row streams its own list, no compaction at sampling time).  Forward,
 //      backward and every further sample_* call of the same preprocess read these lists; none of
@@ -58,9 +58,17 @@ constexpr int PLAN_POINTS_PER_CELL = 16;   // target occupancy of a fine sample 
 // every workgroup of the second.
 constexpr int PLAN_BBOX_BLOCKS = 256;
 
-// tile list entries: sorted Gaussian index | group mask << LIST_IDX_BITS
-constexpr int LIST_IDX_BITS = 28;
+// tile list entries: sorted Gaussian index | WIDE group mask << 24 | NARROW group mask << 28.  Two cut-offs
+// live in one plan: the forward evaluates a pair iff the q <= q_f ellipse reaches the point's group box
+// (narrow mask, also what the group lists hold); the backward of gradients that arrive at second (or
+// third) derivatives uses the q <= q_b ellipse (wide mask; q_b >= q_f): the conic gradient of such a
+// term carries a q^2 prefactor AND its per-Gaussian sum nearly cancels (the plane integral of a
+// derivative of a Gaussian vanishes), so the tail dropped at q = 36 was 2.4e-5 of the largest entry with
+// thousands of points per Gaussian and one-signed incoming gradients (tests/test_fuzz_gpu.py,
+// tools/fuzz_diag.py); at q_b = 44 it is 1e-6.
+constexpr int LIST_IDX_BITS = 24;
 constexpr uint32_t LIST_IDX_MASK = (1u << LIST_IDX_BITS) - 1u;
+constexpr int LIST_WIDE_SHIFT = 24, LIST_NARROW_SHIFT = 28;
 // tile header, 8 words: [0] = count | mode << 30 (entries of the tile list, or record ranges), [1..4] =
 // lengths of the four group lists (list mode)
 constexpr int TILE_HDR_WORDS = 8;
@@ -95,6 +103,7 @@ struct PlanParams {
     uint32_t level_off[PLAN_MAX_LEVELS + 1];   // first counter of every level (copy of PlanLayout::level_off:
                                                // the traversal indexes it by lane)
     uint32_t scan_error;
+    float q_f, q_b;        // the plan's two cut-offs (forward / backward of order >= 2 gradients), q_b >= q_f
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -222,7 +231,7 @@ struct PlanView {
     uint32_t N, list_cap;
     int G0, L;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
-    float q_max;
+    float q_max;                  // list build only: the WIDE cut-off max(q_f, q_b) (the sampling kernels read params->q_f / q_b)
     float* gacc;                  // backward scratch: [8][N] sorted-order gradient sums
 };
 

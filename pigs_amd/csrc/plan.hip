@@ -97,7 +97,8 @@ struct BuildArgs {
     int c, G0, L;
     uint32_t scan_blocks, zero_words;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
-    float q_max;
+    float q_max;          // the WIDE cut-off max(q_f, q_b): levels and candidate boxes are sized for it
+    float q_f, q_b;
     // which halves this build covers
     int do_samples, do_plan;
     int no_lookback;      // test hook: the scan's workgroups never publish; every look-back recomputes
@@ -235,6 +236,8 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         if (a.do_plan) {
             a.params->gg = g;
             a.params->scan_error = 0;
+            a.params->q_f = a.q_f;
+            a.params->q_b = a.q_b;
 #pragma unroll
             for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
         }
@@ -438,7 +441,8 @@ __device__ __forceinline__ Ellipse ellipse_of(float4 A, float cc) {
     e.nb_a = -A.w * __builtin_amdgcn_rcpf(A.z);
     return e;
 }
-__device__ __forceinline__ bool ellipse_reaches_rect(const Ellipse& e, float x0, float y0, float x1, float y1, float q_max) {
+// the minimum of q over the rectangle (NaN for a degenerate conic: every comparison `!(qmin > q_max)` accepts)
+__device__ __forceinline__ float ellipse_min_q_rect(const Ellipse& e, float x0, float y0, float x1, float y1) {
     // clamp(v, lo, hi) with lo <= hi is the median of the three (one v_med3_f32; like the min / max
     // pair it returns a bound when v is NaN)
     const float l = x0 - e.x, r = x1 - e.x, bt = y0 - e.y, tp = y1 - e.y;
@@ -447,7 +451,10 @@ __device__ __forceinline__ bool ellipse_reaches_rect(const Ellipse& e, float x0,
     const float xs = __builtin_amdgcn_fmed3f(e.nb_a * ye, l, r);
     const float q1 = e.a * xe * xe + (2.f * e.b * xe + e.c * ys) * ys;
     const float q2 = e.c * ye * ye + (2.f * e.b * ye + e.a * xs) * xs;
-    return !(fminf(q1, q2) > q_max);
+    return fminf(q1, q2);
+}
+__device__ __forceinline__ bool ellipse_reaches_rect(const Ellipse& e, float x0, float y0, float x1, float y1, float q_max) {
+    return !(ellipse_min_q_rect(e, x0, y0, x1, y1) > q_max);
 }
 __device__ __forceinline__ bool ellipse_reaches_rect(float4 A, float cc, float x0, float y0, float x1, float y1,
                                                      float q_max) {
@@ -666,6 +673,7 @@ struct ListArgs {
     uint32_t* hdr;
     uint32_t* tlist;
     uint32_t* glist;
+    float q_f;            // the narrow cut-off (pv.q_max is the wide one)
 };
 
 __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
@@ -748,28 +756,31 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
                 Ellipse e;
                 e.x = A.x; e.y = A.y; e.a = A.z; e.b = A.w; e.c = B.x; e.nb_c = B.y; e.nb_a = B.z;
                 const uint32_t j = __builtin_bit_cast(uint32_t, B.w);
-                uint32_t gm = 0;
+                uint32_t gm = 0, gf = 0;       // wide (tile list, backward) and narrow (group lists, forward) masks
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // a group without a point (the ragged last tile) has an inverted box: never needed
-                    const bool hit = ellipse_reaches_rect(e, gb[g].x, gb[g].y, gb[g].z, gb[g].w, pv.q_max);
-                    if (hit && gb[g].x <= gb[g].z) gm |= 1u << g;
+                    const float qmin = ellipse_min_q_rect(e, gb[g].x, gb[g].y, gb[g].z, gb[g].w);
+                    if (gb[g].x <= gb[g].z) {
+                        if (!(qmin > pv.q_max)) gm |= 1u << g;
+                        if (!(qmin > a.q_f)) gf |= 1u << g;
+                    }
                 }
-                if (s0 + lane >= sel) gm = 0u;
+                if (s0 + lane >= sel) gm = gf = 0u;
                 const uint64_t km = __ballot(gm != 0u);
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
                 if (n[t] + cnt <= cap) {
-                    if (gm != 0u) tl[n[t] + (uint32_t)lanes_below(km)] = j | (gm << LIST_IDX_BITS);
+                    if (gm != 0u) tl[n[t] + (uint32_t)lanes_below(km)] = j | (gm << LIST_WIDE_SHIFT) | (gf << LIST_NARROW_SHIFT);
                 } else {
                     overflow[t] = true;
                 }
                 n[t] += cnt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const uint64_t mg = __ballot(gm >> g & 1u);
+                    const uint64_t mg = __ballot(gf >> g & 1u);
                     const uint32_t cg = (uint32_t)__builtin_popcountll(mg);
                     if (ng[t][g] + cg <= cap) {
-                        if (gm >> g & 1u) gl[g * cap + ng[t][g] + (uint32_t)lanes_below(mg)] = j;
+                        if (gf >> g & 1u) gl[g * cap + ng[t][g] + (uint32_t)lanes_below(mg)] = j;
                     } else {
                         goverflow[t] = true;
                     }
@@ -796,14 +807,20 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
 
     // A tile list that does not fit while the four group lists do (64 scattered points of a sparse
     // region share few Gaussians: up to 4 x cap distinct ones) is no reason to give the lists up: the
-    // forward reads the group lists only, and the backward walks them as four single-group lists.
-    bool any_overflow = false;
+    // forward reads the group lists only, and the backward walks them as four single-group lists
+    // (TILE_MODE_GROUPS) -- which must then hold the WIDE set: they are rebuilt below.
+    const bool two_cuts = pv.q_max > a.q_f;
+    bool any_rare = false;
+    bool rebuild[LISTS_TPW];
 #pragma unroll
     for (int t = 0; t < LISTS_TPW; ++t) {
-        if (tile0 + (uint32_t)t >= ntiles) continue;
-        overflow[t] = overflow[t] && goverflow[t];        // from here on: the tile needs the ranges fallback
-        any_overflow |= overflow[t];
-        if (!overflow[t] && lane < TILE_HDR_WORDS) {
+        rebuild[t] = false;
+        if (tile0 + (uint32_t)t >= ntiles) { overflow[t] = false; continue; }
+        const bool tl_over = overflow[t];
+        overflow[t] = tl_over && goverflow[t];            // from here on: the tile needs the ranges fallback
+        rebuild[t] = tl_over && !goverflow[t] && two_cuts;
+        any_rare |= overflow[t] || rebuild[t];
+        if (!overflow[t] && !rebuild[t] && lane < TILE_HDR_WORDS) {
             const bool fits = n[t] <= cap;
             uint32_t w = 0;
             if (lane == 0) w = fits ? (n[t] | (TILE_MODE_LIST << TILE_MODE_SHIFT)) : (TILE_MODE_GROUPS << TILE_MODE_SHIFT);
@@ -813,16 +830,23 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
             a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = w;
         }
     }
-    if (!any_overflow) return;
-    // A group list does not fit: that tile keeps the grid's record ranges around ITS box instead (pairs
-    // {first, length}; every Gaussian in them is evaluated for all of its points); when even those do
-    // not fit, the single range of all Gaussians.  A rare path: one tile at a time, not unrolled.
+    if (!any_rare) return;
+    // Rare paths, one tile at a time, not unrolled.  (1) group-lists-only tile under two cut-offs: its
+    // group lists are rebuilt from a walk of the grid around ITS box with the wide cut-off (the forward
+    // then evaluates a few pairs more than q_f asks for in such a tile: harmless).  (2) a group list does
+    // not fit: the tile keeps the grid's record ranges around its box instead (pairs {first, length}; the
+    // sampling kernels test the ranges' records against the group boxes themselves); when even those do
+    // not fit, the single range of all Gaussians.
     for (int t = 0; t < LISTS_TPW; ++t) {
-        const bool mine = __builtin_amdgcn_readfirstlane((int)(t == 0   ? overflow[0]
-                                                               : t == 1 ? overflow[LISTS_TPW > 1 ? 1 : 0]
-                                                               : t == 2 ? overflow[LISTS_TPW > 2 ? 2 : 0]
-                                                                        : overflow[LISTS_TPW > 3 ? 3 : 0])) != 0;
-        if (!mine) continue;
+        const bool mine_rebuild = __builtin_amdgcn_readfirstlane((int)(t == 0   ? rebuild[0]
+                                                                       : t == 1 ? rebuild[LISTS_TPW > 1 ? 1 : 0]
+                                                                       : t == 2 ? rebuild[LISTS_TPW > 2 ? 2 : 0]
+                                                                                : rebuild[LISTS_TPW > 3 ? 3 : 0])) != 0;
+        bool mine = __builtin_amdgcn_readfirstlane((int)(t == 0   ? overflow[0]
+                                                         : t == 1 ? overflow[LISTS_TPW > 1 ? 1 : 0]
+                                                         : t == 2 ? overflow[LISTS_TPW > 2 ? 2 : 0]
+                                                                  : overflow[LISTS_TPW > 3 ? 3 : 0])) != 0;
+        if (!mine && !mine_rebuild) continue;
         float4 gb[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) gb[g] = lds.gbox[t * 4 + g];
@@ -831,6 +855,42 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         const float tx1 = fmaxf(fmaxf(gb[0].z, gb[1].z), fmaxf(gb[2].z, gb[3].z));
         const float ty1 = fmaxf(fmaxf(gb[0].w, gb[1].w), fmaxf(gb[2].w, gb[3].w));
         uint32_t* tl = a.tlist + (size_t)(tile0 + (uint32_t)t) * cap;
+        if (mine_rebuild) {
+            uint32_t* gl = a.glist + (size_t)(tile0 + (uint32_t)t) * 4 * cap;
+            uint32_t ngw[4] = {0u, 0u, 0u, 0u};
+            bool gover = false;
+            traverse(pv, gg, level_mask, loff, tx0, ty0, tx1, ty1, lane, lds.trav, true,
+                     [](int, uint32_t, uint32_t) {},
+                     [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) __attribute__((always_inline)) {
+                const bool have = mask >> lane & 1ull;
+                const Ellipse e = ellipse_of(A, B.x);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool hit = have && gb[g].x <= gb[g].z &&
+                                     !(ellipse_min_q_rect(e, gb[g].x, gb[g].y, gb[g].z, gb[g].w) > pv.q_max);
+                    const uint64_t mg = __ballot(hit);
+                    const uint32_t cg = (uint32_t)__builtin_popcountll(mg);
+                    if (ngw[g] + cg <= cap) {
+                        if (hit) gl[g * cap + ngw[g] + (uint32_t)lanes_below(mg)] = j;
+                    } else {
+                        gover = true;
+                    }
+                    ngw[g] += cg;
+                }
+            });
+            if (!gover) {
+                if (lane < TILE_HDR_WORDS) {
+                    uint32_t w = 0;
+                    if (lane == 0) w = TILE_MODE_GROUPS << TILE_MODE_SHIFT;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (lane == 1 + g) w = ngw[g];
+                    a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = w;
+                }
+                continue;
+            }
+            mine = true;          // the wide group lists do not fit either: ranges
+        }
         uint32_t nr = 0;
         bool fits = true;
         traverse(pv, gg, level_mask, loff, tx0, ty0, tx1, ty1, lane, lds.trav, false,
@@ -873,7 +933,7 @@ __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
 // lanes from STEP on hold none).  A tile in ranges mode has no masks: `ranges_mask()` is called once and
 // returns the functor `mask(idx, have)` that finds an entry's (the caller's kernel keeps its `step` free
 // of that rare case).
-template <int STEP, typename Step, typename RangesMask>
+template <int STEP, bool WIDE, typename Step, typename RangesMask>
 __device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile, int lane, Step&& step,
                                               RangesMask&& ranges_mask) {
     const uint32_t hdr = pv.hdr[(size_t)tile * TILE_HDR_WORDS];
@@ -883,7 +943,7 @@ __device__ __forceinline__ void for_each_step(const PlanView& pv, uint32_t tile,
         for (uint32_t e0 = 0; e0 < count; e0 += STEP) {
             const bool have = lane < STEP && e0 + (uint32_t)lane < count;
             const uint32_t e = have ? slab[e0 + lane] : 0u;
-            step(e & LIST_IDX_MASK, e >> LIST_IDX_BITS, have);
+            step(e & LIST_IDX_MASK, WIDE ? (e >> LIST_WIDE_SHIFT) & 15u : e >> LIST_NARROW_SHIFT, have);
         }
     } else if ((hdr >> TILE_MODE_SHIFT) == TILE_MODE_GROUPS) {
         // the four group lists, one after the other, as lists of single-group entries (a Gaussian that
@@ -1084,6 +1144,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         const uint32_t* slab = pv.tlist + (size_t)tile * pv.list_cap;
         const uint32_t count = h0 & TILE_COUNT_MASK;
         const float INF = __builtin_huge_valf();
+        const float q_f = pv.params->q_f;
         float x0 = valid ? sp.x : INF, x1 = valid ? sp.x : -INF, y0 = valid ? sp.y : INF, y1 = valid ? sp.y : -INF;
         row_box_dpp(x0, x1, y0, y1);                  // every lane: the box of its own row's group
         const bool row_has_points = x0 <= x1;
@@ -1114,7 +1175,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
                 const bool in = base + (uint32_t)i < len;
                 const size_t j = in ? j0 + base + (uint32_t)i : pv.N;
                 const float4 A = pv.rec[2 * j], B = pv.rec[2 * j + 1];
-                const bool hit = in && row_has_points && ellipse_reaches_rect(ellipse_of(A, B.x), x0, y0, x1, y1, pv.q_max);
+                const bool hit = in && row_has_points && ellipse_reaches_rect(ellipse_of(A, B.x), x0, y0, x1, y1, q_f);
                 const uint32_t rm = (uint32_t)(__ballot(hit) >> (16 * g)) & 0xffffu;      // this row's hits
                 if (hit) {
                     const int k = qn + __builtin_popcount(rm & ((1u << i) - 1u));
@@ -1360,8 +1421,11 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     // boxes of its four groups (a range holds every Gaussian NEAR the tile; few reach a given group when
     // the tile's points are scattered, which is when lists overflow).  Built only when the walk meets
     // such a tile, and outside `step`.
+    // gradients that arrive at second / third derivatives (or the trace) use the plan's wide cut-off (plan.h)
+    constexpr bool WIDE = (MASK & (ORD2 | ORD3 | 16)) != 0;
     auto ranges_mask = [&]() {
         const float INF = __builtin_huge_valf();
+        const float q_cut = WIDE ? pv.params->q_b : pv.params->q_f;
         float x0 = valid ? sp.x : INF, x1 = valid ? sp.x : -INF, y0 = valid ? sp.y : INF, y1 = valid ? sp.y : -INF;
         row_box_dpp(x0, x1, y0, y1);
         float4 b0 = make_float4(readlane_f(x0, 0), readlane_f(y0, 0), readlane_f(x1, 0), readlane_f(y1, 0));
@@ -1375,11 +1439,11 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
             uint32_t gm = 0u;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (have && bx[g].x <= bx[g].z && ellipse_reaches_rect(e, bx[g].x, bx[g].y, bx[g].z, bx[g].w, pv.q_max)) gm |= 1u << g;
+                if (have && bx[g].x <= bx[g].z && ellipse_reaches_rect(e, bx[g].x, bx[g].y, bx[g].z, bx[g].w, q_cut)) gm |= 1u << g;
             return gm;
         };
     };
-    for_each_step<BWD_STEP>(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
+    for_each_step<BWD_STEP, WIDE>(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
         const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
         wave_lds_fence();
         if (lane < BWD_STEP) {
@@ -1520,7 +1584,7 @@ static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, c
     a.s_zero_words = (uint32_t)((s.off_starts - s.off_counts) / 4);     // counters + aggregates
 }
 
-static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_max, const void* means,
+static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_f, float q_b, const void* means,
                            const void* conics, const void* values) {
     char* b = (char*)ws;
     a.params = (PlanParams*)(b + p.off_params);
@@ -1537,13 +1601,14 @@ static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_
     a.scan_blocks = p.scan_blocks;
     a.zero_words = (uint32_t)((p.off_starts - p.off_counts) / 4);
     for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.level_off[l] = p.level_off[l];
-    a.q_max = q_max;
+    a.q_f = q_f; a.q_b = q_b;
+    a.q_max = q_b > q_f ? q_b : q_f;
 }
 
 // The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
 // (build_plan) or both in the same four launches, then the tile lists.
 static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_lookback, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
-                     int64_t M, int c, float q_max, const void* means, const void* conics, const void* values,
+                     int64_t M, int c, float q_max, float q_max_b, const void* means, const void* conics, const void* values,
                      const void* samples, hipStream_t stream) {
     if (!samples_supported(M)) return PIGS_ERR_UNSUPPORTED;
     const SamplesLayout s = make_samples_layout(M);
@@ -1555,9 +1620,10 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     if (do_plan) {
         if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
         if (!(q_max > 0.f)) return PIGS_ERR_INVALID;
+        if (!(q_max_b >= q_max)) q_max_b = q_max;      // <= 0 / NaN: one cut-off
         p = make_plan_layout(N, M, c);
         if (!ws || ws_bytes < p.total_bytes) return PIGS_ERR_WORKSPACE;
-        fill_plan_args(a, p, ws, q_max, means, conics, values);
+        fill_plan_args(a, p, ws, q_max, q_max_b, means, conics, values);
     }
     clear_hip_error();
     const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
@@ -1571,7 +1637,8 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
                        stream, a);
     if (do_plan) {
         ListArgs la{};
-        la.pv = make_view(p, ws, q_max);
+        la.pv = make_view(p, ws, a.q_max);
+        la.q_f = q_max;
         la.sv = make_samples_view(s, sws);
         la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
         la.tlist = (uint32_t*)((char*)ws + p.off_tlist);
@@ -1582,13 +1649,13 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
 }
 
 int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream) {
-    return run_build(true, false, false, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, nullptr, nullptr, nullptr, samples, stream);
+    return run_build(true, false, false, false, sws, sws_bytes, nullptr, 0, 0, M, 1, 1.f, 1.f, nullptr, nullptr, nullptr, samples, stream);
 }
 
 int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags, int64_t N, int64_t M, int c,
-               float q_max, const void* means, const void* conics, const void* values, const void* samples,
+               float q_max, float q_max_backward, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream) {
-    return run_build((flags & 1) != 0, true, (flags & 2) != 0, (flags & 4) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, means, conics, values,
+    return run_build((flags & 1) != 0, true, (flags & 2) != 0, (flags & 4) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, q_max_backward, means, conics, values,
                      samples, stream);
 }
 

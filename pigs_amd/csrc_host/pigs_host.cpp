@@ -157,7 +157,7 @@ struct Plan {
     std::shared_ptr<SamplePlan> samples;
     int64_t N = 0, M = 0;
     int c = 1;
-    float q_max = 36.f;
+    float q_max = 36.f, q_max_backward = 36.f;
     std::shared_ptr<PlanPool> pool;      // null: the workspace is not recycled (hipGraph capture)
     PlanPool::Key key;
     hipStream_t build_stream = nullptr;
@@ -172,10 +172,12 @@ struct Plan {
 };
 
 std::shared_ptr<Plan> build_plan(const at::Tensor& means, const at::Tensor& values, const at::Tensor& conics,
-                                 const at::Tensor& samples, float q_max, std::shared_ptr<SamplePlan> sp,
-                                 const at::Tensor& source, const std::shared_ptr<PlanPool>& pool_or_null) {
+                                 const at::Tensor& samples, float q_max, float q_max_backward,
+                                 std::shared_ptr<SamplePlan> sp, const at::Tensor& source,
+                                 const std::shared_ptr<PlanPool>& pool_or_null) {
     auto plan = std::make_shared<Plan>();
     plan->N = means.size(0); plan->M = samples.size(0); plan->c = (int)values.size(1); plan->q_max = q_max;
+    plan->q_max_backward = q_max_backward > q_max ? q_max_backward : q_max;
     const size_t nbytes = pigs_plan_workspace_bytes(plan->N, plan->M, plan->c);
     if (nbytes == 0)
         throw PigsFailure("binned path does not support N=" + std::to_string(plan->N) + " M=" + std::to_string(plan->M) +
@@ -191,7 +193,7 @@ std::shared_ptr<Plan> build_plan(const at::Tensor& means, const at::Tensor& valu
     if (plan->workspace.defined()) flags |= PIGS_BUILD_PLAN_WS_CLEAN;
     else plan->workspace = at::empty({(int64_t)nbytes}, means.options().dtype(at::kByte));
     check(pigs_plan_build(plan->workspace.data_ptr(), nbytes, sp->workspace.data_ptr(), (size_t)sp->workspace.numel(),
-                          flags, plan->N, plan->M, plan->c, q_max, ptr(means), ptr(conics), ptr(values), ptr(samples),
+                          flags, plan->N, plan->M, plan->c, q_max, plan->q_max_backward, ptr(means), ptr(conics), ptr(values), ptr(samples),
                           stream),
           "pigs_plan_build");
     sp->built = true;
@@ -334,7 +336,7 @@ struct Core {
 
     bool debug;
     int fuse, backend;
-    float q_max, q_max3;
+    float q_max, q_max3, q_max_b;
     int reuse;
     bool bound = false;
     at::Tensor means, values, conics, samples, samples_source;
@@ -344,8 +346,9 @@ struct Core {
     Outs cache;
     static bool warned_samples_grad;
 
-    Core(bool debug_, int fuse_, int backend_, double q_max_, double q_max3_, int reuse_)
-        : debug(debug_), fuse(fuse_), backend(backend_), q_max((float)q_max_), q_max3((float)q_max3_), reuse(reuse_) {
+    Core(bool debug_, int fuse_, int backend_, double q_max_, double q_max3_, double q_max_b_, int reuse_)
+        : debug(debug_), fuse(fuse_), backend(backend_), q_max((float)q_max_), q_max3((float)q_max3_),
+          q_max_b((float)q_max_b_), reuse(reuse_) {
         if (pigs_abi_version() != PIGS_ABI_VERSION)
             throw PigsFailure("libpigs_amd.so: ABI version " + std::to_string(pigs_abi_version()) + " != " +
                               std::to_string(PIGS_ABI_VERSION) + "; rebuild");
@@ -425,8 +428,8 @@ struct Core {
         if (!sp && !cap && reuse > 0)
             for (auto& p : sample_plans)
                 if (p->matches(samples_source)) { sp = p; break; }
-        auto pl = build_plan(means.detach(), values.detach(), conics.detach(), samples, q, sp, samples_source,
-                             cap ? nullptr : pool);
+        auto pl = build_plan(means.detach(), values.detach(), conics.detach(), samples, q, q_max_b > q ? q_max_b : q, sp,
+                             samples_source, cap ? nullptr : pool);
         if (reuse > 0 && !cap) {
             std::vector<std::shared_ptr<SamplePlan>> next{pl->samples};
             for (auto& p : sample_plans)
@@ -553,14 +556,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("M", &Plan::M)
         .def_readonly("c", &Plan::c)
         .def_readonly("q_max", &Plan::q_max)
+        .def_readonly("q_max_backward", &Plan::q_max_backward)
         .def_readonly("other_stream_used", &Plan::other_stream_used)
         .def("scan_took_slow_path", [](const Plan& p) {
             return error_flag(p.samples->workspace, pigs_samples_error_offset()) != 0 ||
                    error_flag(p.workspace, pigs_plan_error_offset()) != 0;
         });
     py::class_<Core>(m, "SamplerCore")
-        .def(py::init<bool, int, int, double, double, int>(), py::arg("debug"), py::arg("fuse"), py::arg("backend"),
-             py::arg("q_max"), py::arg("q_max_order3"), py::arg("reuse_samples"))
+        .def(py::init<bool, int, int, double, double, double, int>(), py::arg("debug"), py::arg("fuse"), py::arg("backend"),
+             py::arg("q_max"), py::arg("q_max_order3"), py::arg("q_max_backward"), py::arg("reuse_samples"))
         .def("preprocess", &Core::preprocess)
         .def("get", &Core::get)
         .def("sample", &Core::sample)

@@ -165,15 +165,16 @@ class Plan:
     once built; autograd nodes keep a reference, so later ``preprocess`` calls never disturb a
     pending backward."""
 
-    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "_pool", "_pool_key", "build_stream",
-                 "other_stream_used")
+    __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "q_max_backward", "_pool", "_pool_key",
+                 "build_stream", "other_stream_used")
 
     BUILD_SAMPLES, WS_CLEAN = 1, 2      # pigs_amd.h: PIGS_BUILD_SAMPLES, PIGS_BUILD_PLAN_WS_CLEAN
 
     def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None, pool=None,
-                 recorded_only=False):
+                 recorded_only=False, q_max_backward=None):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
+        self.q_max_backward = max(self.q_max, float(q_max_backward if q_max_backward is not None else q_max))
         self._pool = None
         self.other_stream_used = False
         key = (self.N, self.M, self.c)
@@ -197,7 +198,7 @@ class Plan:
                 self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
             sws = sample_plan.workspace
             rc = lib.pigs_plan_build(_ptr(self.workspace), nbytes, _ptr(sws), sws.numel(),
-                                     flags, self.N, self.M, self.c, self.q_max,
+                                     flags, self.N, self.M, self.c, self.q_max, self.q_max_backward,
                                      _ptr(means), _ptr(conics), _ptr(values), _ptr(samples), stream)
         _lib.check(rc, "pigs_plan_build")
         # a build that was only RECORDED into a hipGraph has not run: nothing eager may rely on it
@@ -369,7 +370,10 @@ class GaussianSampler:
     compute third derivatives use the wider ``q_max_order3``, default q_max + 8, through a second
     plan built on first use: dropped terms carry a q^1.5 prefactor there, q^2.5 in its conic
     gradient -- tools/fuzz_stats.py: 2 of 300 adversarial cases left the 1e-5 bar at 36, none at
-    40); ``"auto"`` picks
+    40; the backward of gradients that arrive at second derivatives (or the trace) uses
+    ``q_max_backward``, default q_max + 8, through wider group masks kept in the SAME plan: the conic
+    gradient of such a term carries q^2 and its sum nearly cancels -- tools/fuzz_diag.py: 2.4e-5 of the
+    largest entry at 36, 1e-6 at 44); ``"auto"`` picks
     binned for float32, d = 2, c <= 2 once N*M >= 2**26 pairs, where the plan pays for itself.
 
     ``reuse_samples`` (extension, keyword only; binned path): when ``preprocess`` is called again with a
@@ -413,7 +417,7 @@ class GaussianSampler:
     _warned_aggregate = False
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
-                 reuse_samples=True, unpinned_aggregate=False, host=None):
+                 q_max_backward=None, reuse_samples=True, unpinned_aggregate=False, host=None):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):
@@ -432,6 +436,9 @@ class GaussianSampler:
         self.q_max_order3 = float(q_max_order3) if q_max_order3 is not None else self.q_max + 8.0
         if self.q_max_order3 < self.q_max:
             raise ValueError("q_max_order3 must not be below q_max")
+        self.q_max_backward = float(q_max_backward) if q_max_backward is not None else self.q_max + 8.0
+        if self.q_max_backward < self.q_max:
+            raise ValueError("q_max_backward must not be below q_max")
         self.reuse_samples = 4 if reuse_samples is True else max(0, int(reuse_samples))
         self.unpinned_aggregate = bool(unpinned_aggregate)
         self._neighbors = None
@@ -446,7 +453,8 @@ class GaussianSampler:
         self._core = None
         if host == "native":
             self._core = _load_native_host().SamplerCore(self.debug, _FUSE_CODES[fuse], _BACKEND_CODES[backend],
-                                                         self.q_max, self.q_max_order3, self.reuse_samples)
+                                                         self.q_max, self.q_max_order3, self.q_max_backward,
+                                                         self.reuse_samples)
 
     # state lives in the native core when there is one
     @property
@@ -551,7 +559,7 @@ class GaussianSampler:
         pool = None if capturing else self._plan_pool
         with torch.no_grad():
             plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source, pool,
-                        recorded_only=capturing)
+                        recorded_only=capturing, q_max_backward=max(q_max, self.q_max_backward))
         if self.reuse_samples and not capturing:
             self._st_sample_plans = [plan.samples] + [p for p in self._st_sample_plans if p is not plan.samples]
             del self._st_sample_plans[self.reuse_samples:]

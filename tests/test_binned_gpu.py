@@ -532,7 +532,7 @@ def test_scan_recompute_path_gives_the_same_plan(Sampler):
     vp = lambda x: ctypes.c_void_p(x.data_ptr())
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for flags, expect_flag in ((1, False), (1 | 4, True)):
-        rc = lib.pigs_plan_build(vp(ws), ws.numel(), vp(sws), sws.numel(), flags, N, M, 1, 36.0,
+        rc = lib.pigs_plan_build(vp(ws), ws.numel(), vp(sws), sws.numel(), flags, N, M, 1, 36.0, 44.0,
                                  vp(t[0]), vp(t[2]), vp(t[1]), vp(t[3]), stream)
         assert rc == 0
         torch.cuda.synchronize()
