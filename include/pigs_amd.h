@@ -180,18 +180,33 @@ int pigs_plan_layout_info(int64_t N, int64_t M, int c, int64_t info[6]);
  *   out_i = sum_j a_ij (transform features_j + distance_transform [e_ij ; g_ij e_ij]),  e_ij = Fourier embedding
  *   of mu_j - mu_i with `frequencies` (E = 4F + 1 entries), g_ij = exp(-q_ij / 2).
  * The neighbour relation is kept as index lists -- `cap` int32 slots per Gaussian, by rows (the j of an
- * i) and by columns (the i that hold a j) -- never as an [N, N, ...] tensor.
+ * i) and by columns (the i that hold a j).
  *
- * pigs_aggregate_lists: counts [N] and lists [N][cap] by rows and by columns; *overflow (int32, zeroed
- *   by the caller) is set when a list did not fit `cap` (it is then truncated).
+ * pigs_aggregate_lists: counts [N] and lists [N][cap] by rows and by columns.  Up to N = 2048 every pair
+ *   is tested (two launches, lists ascending, `workspace` and `flags` unused: cap = N can never overflow and
+ *   needs no counting pass); beyond, through the sampler's multi-level Gaussian grid in `workspace`
+ *   (pigs_aggregate_workspace_bytes(dtype, N) bytes, 256-byte aligned; 0 = unsupported N): `flags` & PIGS_AGGREGATE_BUILD_GRID (re)builds the grid from
+ *   `means` / `conics` first (4 launches; float64 inputs are binned through float32 copies with a
+ *   widened cut-off -- the grid only nominates candidates, every pair is tested in the caller's dtype;
+ *   this presumes ellipses far larger than the float32 spacing of the coordinates), without it the
+ *   workspace must hold the grid of the same Gaussians.  With row_lists == col_lists == NULL only the
+ *   counts are written (the FULL list lengths: the caller sizes `cap` from their maximum, then calls
+ *   again with the lists).  *overflow (int32, zeroed by the caller) is set when a list did not fit
+ *   `cap` (it is then truncated).  List order is the grid's (not ascending; may differ between builds).
  * pigs_aggregate_forward: out [N][L], and for the backward lse [N] (log-sum-exp of the scaled scores)
  *   and acc [N][L + 2E] = (sum_j a_ij features_j ; sum_j a_ij [e_ij ; g_ij e_ij]).
- * pigs_aggregate_backward: given dacc [N][L + 2E] = gout [transform | distance_transform] and
- *   D [N] = <dacc_i, acc_i> (plain GEMMs, left to the caller, as are d transform = gout^T acc[:, :L] and
- *   d distance_transform = gout^T acc[:, L:]), writes g_features [N][L], g_queries [N][K], g_keys [N][K]
- *   and g_freq_rows [N][F] (summed over the rows by the caller: no atomics, deterministic).
+ * pigs_aggregate_backward: the whole backward from gout [N][L] (4 launches; 5 for N > 2048): all six
+ *   gradients -- g_features [N][L], g_transform [L][L], g_queries [N][K], g_keys [N][K], g_frequencies [F],
+ *   g_distance_transform [L][2E].  `scratch` (pigs_aggregate_backward_scratch_bytes(dtype, N, L, F) bytes)
+ *   holds dacc = gout [transform | distance_transform], D_i = <dacc_i, acc_i> and the per-row shares of the
+ *   frequency gradient between the launches.  The per-Gaussian gradients are gathers (no atomics); the
+ *   three sums over the Gaussians are plain sums up to N = 2048 and atomic sums of 2048-Gaussian
+ *   partials beyond.
  */
+#define PIGS_AGGREGATE_BUILD_GRID 1
+size_t pigs_aggregate_workspace_bytes(int dtype, int64_t N);
 int pigs_aggregate_lists(int dtype, int64_t N, int64_t cap, const void* means, const void* conics, double q_max,
+                         void* workspace, size_t workspace_bytes, int flags,
                          int32_t* row_counts, int32_t* row_lists, int32_t* col_counts, int32_t* col_lists,
                          int32_t* overflow, void* stream);
 
@@ -201,12 +216,15 @@ int pigs_aggregate_forward(int dtype, int64_t N, int64_t cap, int L, int K, int 
                            const void* frequencies, const void* distance_transform,
                            void* out, void* lse, void* acc, void* stream);
 
+size_t pigs_aggregate_backward_scratch_bytes(int dtype, int64_t N, int L, int F);
 int pigs_aggregate_backward(int dtype, int64_t N, int64_t cap, int L, int K, int F,
                             const void* means, const void* conics, const int32_t* row_counts, const int32_t* row_lists,
                             const int32_t* col_counts, const int32_t* col_lists,
-                            const void* features, const void* queries, const void* keys, const void* frequencies,
-                            const void* lse, const void* dacc, const void* D,
-                            void* g_features, void* g_queries, void* g_keys, void* g_freq_rows, void* stream);
+                            const void* features, const void* transform, const void* queries, const void* keys,
+                            const void* frequencies, const void* distance_transform,
+                            const void* lse, const void* acc, const void* gout, void* scratch, size_t scratch_bytes,
+                            void* g_features, void* g_transform, void* g_queries, void* g_keys, void* g_frequencies,
+                            void* g_distance_transform, void* stream);
 
 #ifdef __cplusplus
 }

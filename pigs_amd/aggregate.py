@@ -15,9 +15,9 @@ oracle/aggregate_torch.py):
   Fourier embedding of mu_j - mu_i and g_ij = exp(-q_ij / 2) the density of Gaussian j at the centre of i;
 * out_i = sum_j a_ij m_ij.
 
-The neighbour relation lives in index lists (``NeighborLists``); no [N, N, ...] tensor exists at any
-point.  The three small GEMMs of the backward (gout @ [transform | distance_transform], gout^T @ acc)
-are torch.matmul; everything per (i, j) pair runs in the kernels.  d = 2, float32 / float64.
+The neighbour relation lives in index lists (``NeighborLists``: [N, cap] with cap = the longest list,
+found by a counting pass).  Forward = one launch, backward = four (the three small GEMMs
+gout @ [transform | distance_transform], gout^T @ acc included).  d = 2, float32 / float64.
 """
 import ctypes
 
@@ -26,7 +26,8 @@ import torch
 from . import _lib
 
 _DTYPES = {torch.float32: _lib.PIGS_F32, torch.float64: _lib.PIGS_F64}
-MAX_NEIGHBORS = {torch.float32: 8192, torch.float64: 4096}      # the backward parks two values per neighbour in LDS
+BRUTE_MAX = 2048     # pigs_amd/csrc/aggregate.hip AGG_BRUTE_MAX: up to here every pair is tested, cap = N
+MAX_NEIGHBORS = {torch.float32: 8192, torch.float64: 4096}      # slab size when the counting pass cannot be read back (capture)
 
 
 def _ptr(t):
@@ -38,9 +39,16 @@ def _stream(device):
 
 
 class NeighborLists:
-    """Index lists of the neighbour relation: by rows (the j of an i) and by columns (the i of a j)."""
+    """Index lists of the neighbour relation: by rows (the j of an i) and by columns (the i of a j),
+    ``cap`` int32 slots per Gaussian.  Up to N = 2048 (the model's sizes) every pair is tested and cap = N:
+    two launches, nothing read back.  Beyond: built through the sampler's multi-level Gaussian grid (one wave per
+    Gaussian walks the cells around its centre / its ellipse; pigs_amd/csrc/aggregate.hip), in two passes:
+    a counting pass, then -- with ``cap`` = the longest list rounded up to 64, read back ONCE (the only
+    host synchronisation of ``preprocess_aggregate``) -- the lists themselves.  ``cap`` given (or a hipGraph
+    being captured, where nothing may be read back): one pass into slabs of that size, and a list that does
+    not fit sets ``overflow`` (checked by :meth:`check`; debug mode calls it)."""
 
-    def __init__(self, means, conics, q_max):
+    def __init__(self, means, conics, q_max, cap=None):
         lib = _lib.load()
         if means.dim() != 2 or means.shape[1] != 2:
             raise NotImplementedError("aggregate_neighbors is implemented for d = 2")
@@ -48,20 +56,43 @@ class NeighborLists:
             raise TypeError(f"dtype {means.dtype} is not supported (float32 / float64)")
         self.means = means.detach().contiguous()
         self.conics = conics.detach().reshape(means.shape[0], 3).contiguous()
-        self.N = means.shape[0]
-        self.cap = max(1, min(self.N, MAX_NEIGHBORS[means.dtype]))
+        self.N = N = means.shape[0]
         dev = means.device
-        self.row_counts = torch.empty(self.N, dtype=torch.int32, device=dev)
-        self.col_counts = torch.empty(self.N, dtype=torch.int32, device=dev)
-        self.row_lists = torch.empty((self.N, self.cap), dtype=torch.int32, device=dev)
-        self.col_lists = torch.empty((self.N, self.cap), dtype=torch.int32, device=dev)
+        dt = _DTYPES[means.dtype]
+        nbytes = lib.pigs_aggregate_workspace_bytes(dt, N)
+        if nbytes == 0:
+            raise _lib.PigsError(f"aggregate_neighbors does not support N={N}")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.row_counts = torch.empty(N, dtype=torch.int32, device=dev)
+        self.col_counts = torch.empty(N, dtype=torch.int32, device=dev)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.pigs_aggregate_lists(_DTYPES[means.dtype], self.N, self.cap, _ptr(self.means), _ptr(self.conics),
-                                          float(q_max), _ptr(self.row_counts), _ptr(self.row_lists),
-                                          _ptr(self.col_counts), _ptr(self.col_lists), _ptr(self.overflow),
-                                          _stream(dev))
-        _lib.check(rc, "pigs_aggregate_lists")
+        self.row_lists = self.col_lists = None
+
+        def run(flags, cap_, with_lists):
+            with torch.cuda.device(dev):
+                rc = lib.pigs_aggregate_lists(dt, N, cap_, _ptr(self.means), _ptr(self.conics), float(q_max),
+                                              _ptr(self.workspace), nbytes, flags, _ptr(self.row_counts),
+                                              _ptr(self.row_lists) if with_lists else ctypes.c_void_p(0),
+                                              _ptr(self.col_counts),
+                                              _ptr(self.col_lists) if with_lists else ctypes.c_void_p(0),
+                                              _ptr(self.overflow), _stream(dev))
+            _lib.check(rc, "pigs_aggregate_lists")
+
+        flags = 1                                                  # PIGS_AGGREGATE_BUILD_GRID
+        if cap is None and N <= BRUTE_MAX:
+            cap = max(1, N)                                        # every pair is tested; a slab of N cannot overflow
+        if cap is None and N > 0 and torch.cuda.is_current_stream_capturing():
+            cap = min(N, MAX_NEIGHBORS[means.dtype])               # nothing can be read back inside a capture
+        if cap is None and N > 0:
+            run(flags, 1, False)                                   # counting pass (full lengths)
+            flags = 0
+            longest = int(torch.maximum(self.row_counts.max(), self.col_counts.max()).item())
+            cap = max(64, (longest + 63) // 64 * 64)
+        self.cap = max(1, int(cap if cap is not None else 1))
+        self.row_lists = torch.empty((N, self.cap), dtype=torch.int32, device=dev)
+        self.col_lists = torch.empty((N, self.cap), dtype=torch.int32, device=dev)
+        if N > 0:
+            run(flags, self.cap, True)
 
     def check(self):
         """Synchronising check (debug mode): a neighbour list longer than its slab was truncated."""
@@ -102,22 +133,21 @@ class _Aggregate(torch.autograd.Function):
         N, L, K, F, E = ctx.dims
         dt = f.dtype
         gout = gout.to(dt).contiguous()
-        dacc = gout @ torch.cat((tr, dist), dim=1)                 # [N, L + 2E]
-        D = (dacc * acc).sum(dim=1).contiguous()
-        g_f = torch.empty_like(f)
-        g_q = torch.empty_like(q)
-        g_k = torch.empty_like(k)
-        g_fr_rows = torch.empty((N, F), dtype=dt, device=f.device)
+        g_f, g_tr, g_q, g_k, g_fr, g_dist = (torch.empty_like(t) for t in (f, tr, q, k, fr, dist))
+        nbytes = lib.pigs_aggregate_backward_scratch_bytes(_DTYPES[dt], N, L, F)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
         with torch.cuda.device(f.device):
             rc = lib.pigs_aggregate_backward(_DTYPES[dt], N, nb.cap, L, K, F, _ptr(nb.means), _ptr(nb.conics),
                                              _ptr(nb.row_counts), _ptr(nb.row_lists), _ptr(nb.col_counts),
-                                             _ptr(nb.col_lists), _ptr(f), _ptr(q), _ptr(k), _ptr(fr), _ptr(lse),
-                                             _ptr(dacc), _ptr(D), _ptr(g_f), _ptr(g_q), _ptr(g_k), _ptr(g_fr_rows),
+                                             _ptr(nb.col_lists), _ptr(f), _ptr(tr), _ptr(q), _ptr(k), _ptr(fr), _ptr(dist),
+                                             _ptr(lse), _ptr(acc), _ptr(gout), _ptr(scratch), nbytes,
+                                             _ptr(g_f), _ptr(g_tr), _ptr(g_q), _ptr(g_k), _ptr(g_fr), _ptr(g_dist),
                                              _stream(f.device))
         _lib.check(rc, "pigs_aggregate_backward")
-        g_tr = gout.t() @ acc[:, :L]
-        g_dist = gout.t() @ acc[:, L:]
-        grads = (g_f, g_tr, g_q, g_k, g_fr_rows.sum(dim=0), g_dist)
+        if N == 0:
+            for g in (g_tr, g_fr, g_dist):
+                g.zero_()
+        grads = (g_f, g_tr, g_q, g_k, g_fr, g_dist)
         return (None,) + tuple(g.to(d) for g, d in zip(grads, ctx.in_dtypes))
 
 

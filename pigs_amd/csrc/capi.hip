@@ -135,20 +135,24 @@ int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samp
 static int aggregate_sizes_ok(int dtype, int64_t N, int64_t cap, int L, int K, int F) {
     if (dtype != PIGS_F32 && dtype != PIGS_F64) return PIGS_ERR_UNSUPPORTED;
     if (N < 0 || cap < 1 || L < 1 || K < 1 || F < 0) return PIGS_ERR_INVALID;
-    if (L + 2 * (4 * F + 1) > 128 || N > 0x7fffffffLL) return PIGS_ERR_UNSUPPORTED;   // two components per lane
-    if (2 * cap * (dtype == PIGS_F64 ? 8 : 4) > 64 * 1024) return PIGS_ERR_UNSUPPORTED;   // the backward's LDS
+    if (L + 2 * (4 * F + 1) > 128 || L + K > 128 || K + F > 128 || N > 0x7fffffffLL) return PIGS_ERR_UNSUPPORTED;   // two components per lane
     return PIGS_OK;
 }
 
+size_t pigs_aggregate_workspace_bytes(int dtype, int64_t N) {
+    if ((dtype != PIGS_F32 && dtype != PIGS_F64) || N < 0) return 0;
+    return aggregate_workspace_bytes(dtype, N);
+}
+
 int pigs_aggregate_lists(int dtype, int64_t N, int64_t cap, const void* means, const void* conics, double q_max,
-                         int32_t* row_counts, int32_t* row_lists, int32_t* col_counts, int32_t* col_lists,
-                         int32_t* overflow, void* stream) {
+                         void* workspace, size_t workspace_bytes, int flags, int32_t* row_counts, int32_t* row_lists,
+                         int32_t* col_counts, int32_t* col_lists, int32_t* overflow, void* stream) {
     if (dtype != PIGS_F32 && dtype != PIGS_F64) return PIGS_ERR_UNSUPPORTED;
     if (N < 0 || cap < 1 || !(q_max > 0)) return PIGS_ERR_INVALID;
-    if (N > 0 && (!means || !conics || !row_counts || !row_lists || !col_counts || !col_lists || !overflow))
-        return PIGS_ERR_INVALID;
-    return aggregate_lists(dtype, N, cap, means, conics, q_max, row_counts, row_lists, col_counts, col_lists, overflow,
-                           (hipStream_t)stream);
+    if ((row_lists == nullptr) != (col_lists == nullptr)) return PIGS_ERR_INVALID;
+    if (N > 0 && (!means || !conics || !row_counts || !col_counts || (row_lists && !overflow))) return PIGS_ERR_INVALID;
+    return aggregate_lists(dtype, N, cap, means, conics, q_max, workspace, workspace_bytes, flags, row_counts, row_lists,
+                           col_counts, col_lists, overflow, (hipStream_t)stream);
 }
 
 int pigs_aggregate_forward(int dtype, int64_t N, int64_t cap, int L, int K, int F, const void* means, const void* conics,
@@ -168,25 +172,34 @@ int pigs_aggregate_forward(int dtype, int64_t N, int64_t cap, int L, int K, int 
     return aggregate_forward(a, (hipStream_t)stream);
 }
 
+size_t pigs_aggregate_backward_scratch_bytes(int dtype, int64_t N, int L, int F) {
+    if ((dtype != PIGS_F32 && dtype != PIGS_F64) || N < 0 || L < 1 || F < 0) return 0;
+    return aggregate_backward_scratch_bytes(dtype, N, L, F);
+}
+
 int pigs_aggregate_backward(int dtype, int64_t N, int64_t cap, int L, int K, int F, const void* means,
                             const void* conics, const int32_t* row_counts, const int32_t* row_lists,
                             const int32_t* col_counts, const int32_t* col_lists, const void* features,
-                            const void* queries, const void* keys, const void* frequencies, const void* lse,
-                            const void* dacc, const void* D, void* g_features, void* g_queries, void* g_keys,
-                            void* g_freq_rows, void* stream) {
+                            const void* transform, const void* queries, const void* keys, const void* frequencies,
+                            const void* distance_transform, const void* lse, const void* acc, const void* gout,
+                            void* scratch, size_t scratch_bytes, void* g_features, void* g_transform, void* g_queries,
+                            void* g_keys, void* g_frequencies, void* g_distance_transform, void* stream) {
     const int rc = aggregate_sizes_ok(dtype, N, cap, L, K, F);
     if (rc != PIGS_OK) return rc;
-    if (N > 0 && (!means || !conics || !row_counts || !row_lists || !col_counts || !col_lists || !features || !queries ||
-                  !keys || (F > 0 && !frequencies) || !lse || !dacc || !D || !g_features || !g_queries || !g_keys ||
-                  (F > 0 && !g_freq_rows)))
+    if (N > 0 && (!means || !conics || !row_counts || !row_lists || !col_counts || !col_lists || !features || !transform ||
+                  !queries || !keys || (F > 0 && !frequencies) || !distance_transform || !lse || !acc || !gout || !scratch ||
+                  !g_features || !g_transform || !g_queries || !g_keys || (F > 0 && !g_frequencies) || !g_distance_transform))
         return PIGS_ERR_INVALID;
+    if (N > 0 && scratch_bytes < aggregate_backward_scratch_bytes(dtype, N, L, F)) return PIGS_ERR_WORKSPACE;
     AggregateArgs a{};
     a.dtype = dtype; a.N = N; a.cap = cap; a.L = L; a.K = K; a.F = F;
     a.means = means; a.conics = conics; a.row_counts = row_counts; a.row_lists = row_lists;
     a.col_counts = col_counts; a.col_lists = col_lists;
-    a.features = features; a.queries = queries; a.keys = keys; a.frequencies = frequencies;
-    a.lse = const_cast<void*>(lse); a.dacc = dacc; a.D = D;
-    a.g_features = g_features; a.g_queries = g_queries; a.g_keys = g_keys; a.g_freq_rows = g_freq_rows;
+    a.features = features; a.transform = transform; a.queries = queries; a.keys = keys; a.frequencies = frequencies;
+    a.distance_transform = distance_transform;
+    a.lse = const_cast<void*>(lse); a.acc = const_cast<void*>(acc); a.gout = gout; a.scratch = scratch;
+    a.g_features = g_features; a.g_transform = g_transform; a.g_queries = g_queries; a.g_keys = g_keys;
+    a.g_frequencies = g_frequencies; a.g_distance_transform = g_distance_transform;
     return aggregate_backward(a, (hipStream_t)stream);
 }
 

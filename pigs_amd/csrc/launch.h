@@ -30,13 +30,16 @@ struct AggregateArgs {
     const void *means, *conics;
     const int32_t *row_counts, *row_lists, *col_counts, *col_lists;
     const void *features, *transform, *queries, *keys, *frequencies, *distance_transform;
-    void *out, *lse, *acc;                         // forward outputs (the backward reads lse)
-    const void *dacc, *D;                          // backward inputs
-    void *g_features, *g_queries, *g_keys, *g_freq_rows;
+    void *out, *lse, *acc;                         // forward outputs (the backward reads lse and acc)
+    const void* gout;                              // backward: incoming gradient [N][L]
+    void* scratch;                                 // backward: dacc [N][W], D [N], per-row d frequencies [N][F]
+    void *g_features, *g_transform, *g_queries, *g_keys, *g_frequencies, *g_distance_transform;
 };
-int aggregate_lists(int dtype, int64_t N, int64_t cap, const void* means, const void* conics, double q_max,
-                    int32_t* row_counts, int32_t* row_lists, int32_t* col_counts, int32_t* col_lists, int32_t* overflow,
-                    hipStream_t stream);
+size_t aggregate_backward_scratch_bytes(int dtype, int64_t N, int L, int F);
+size_t aggregate_workspace_bytes(int dtype, int64_t N);
+int aggregate_lists(int dtype, int64_t N, int64_t cap, const void* means, const void* conics, double q_max, void* workspace,
+                    size_t workspace_bytes, int flags, int32_t* row_counts, int32_t* row_lists, int32_t* col_counts,
+                    int32_t* col_lists, int32_t* overflow, hipStream_t stream);
 int aggregate_forward(const AggregateArgs& a, hipStream_t stream);
 int aggregate_backward(const AggregateArgs& a, hipStream_t stream);
 
@@ -53,6 +56,10 @@ int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, 
                   float q_max, int mask, const void* const* gout, void* g_means, void* g_conics, void* g_values,
                   hipStream_t stream);
 int plan_layout_info(int64_t N, int64_t M, int c, int64_t* info);
+// the Gaussian grid alone (aggregate.hip): plan.hip
+size_t aggregate_grid_bytes(int64_t N);
+int aggregate_grid_build(void* ws, size_t ws_bytes, int64_t N, float q_grid, const float* means, const float* conics,
+                         hipStream_t stream);
 size_t samples_error_offset();
 size_t plan_error_offset();
 

@@ -325,6 +325,156 @@ Outs sample_apply(const at::Tensor& means, const at::Tensor& values, const at::T
 }
 
 // ---------------------------------------------------------------------------------------------
+// preprocess_aggregate / aggregate_neighbors (model_pn.py:257-264; parity unpinned: this repository's own
+// definition, pigs_amd/csrc/aggregate.hip).  Same structure as pigs_amd/aggregate.py.
+// ---------------------------------------------------------------------------------------------
+constexpr int64_t AGG_BRUTE_MAX = 2048;      // aggregate.hip: up to here every pair is tested and cap = N
+
+struct NeighborLists {
+    at::Tensor means, conics, workspace, row_counts, col_counts, row_lists, col_lists, overflow;
+    int64_t N = 0, cap = 1;
+
+    NeighborLists(const at::Tensor& means_in, const at::Tensor& conics_in, double q_max, int64_t cap_in) {
+        if (means_in.dim() != 2 || means_in.size(1) != 2) raise_py(PyExc_NotImplementedError, "aggregate_neighbors is implemented for d = 2");
+        at::AutoGradMode no_grad(false);
+        means = means_in.detach().contiguous();
+        N = means.size(0);
+        conics = conics_in.detach().reshape({N, 3}).contiguous();
+        const int dt = dtype_code(means);
+        const size_t nbytes = pigs_aggregate_workspace_bytes(dt, N);
+        if (nbytes == 0) throw PigsFailure("aggregate_neighbors does not support N=" + std::to_string(N));
+        const auto iopt = means.options().dtype(at::kInt);
+        workspace = at::empty({(int64_t)nbytes}, means.options().dtype(at::kByte));
+        row_counts = at::empty({N}, iopt);
+        col_counts = at::empty({N}, iopt);
+        overflow = at::zeros({1}, iopt);
+        c10::DeviceGuard guard(means.device());
+        const hipStream_t stream = current_stream(means);
+        auto run = [&](int flags, int64_t cap_, bool with_lists) {
+            check(pigs_aggregate_lists(dt, N, cap_, ptr(means), ptr(conics), q_max, workspace.data_ptr(), nbytes, flags,
+                                       (int32_t*)ptr(row_counts), with_lists ? (int32_t*)ptr(row_lists) : nullptr,
+                                       (int32_t*)ptr(col_counts), with_lists ? (int32_t*)ptr(col_lists) : nullptr,
+                                       (int32_t*)ptr(overflow), stream),
+                  "pigs_aggregate_lists");
+        };
+        int flags = PIGS_AGGREGATE_BUILD_GRID;
+        int64_t c = cap_in;
+        if (c <= 0 && N <= AGG_BRUTE_MAX) c = N > 0 ? N : 1;
+        if (c <= 0 && capturing(stream)) c = std::min<int64_t>(N, means.scalar_type() == at::kDouble ? 4096 : 8192);
+        if (c <= 0) {        // counting pass; the longest list is read back once (the one synchronisation)
+            run(flags, 1, false);
+            flags = 0;
+            const int64_t longest = at::maximum(row_counts.max(), col_counts.max()).item<int64_t>();
+            c = std::max<int64_t>(64, (longest + 63) / 64 * 64);
+        }
+        cap = std::max<int64_t>(1, c);
+        row_lists = at::empty({N, cap}, iopt);
+        col_lists = at::empty({N, cap}, iopt);
+        if (N > 0) run(flags, cap, true);
+    }
+    void check_overflow() const {
+        if (overflow.item<int32_t>() != 0)
+            throw PigsFailure("aggregate: a Gaussian has more than " + std::to_string(cap) + " neighbours (list truncated)");
+    }
+};
+
+struct AggregateBackward : public torch::autograd::Node {
+    std::shared_ptr<NeighborLists> nb;
+    at::Tensor f, tr, q, k, fr, dist, lse, acc;     // converted, contiguous, detached
+    uint32_t versions[6] = {0, 0, 0, 0, 0, 0};
+    at::ScalarType in_dtypes[6];
+    int64_t N = 0;
+    int L = 0, K = 0, F = 0;
+
+    std::string name() const override { return "PigsAggregateBackward"; }
+
+    torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
+        if (!f.defined()) throw std::runtime_error("aggregate_neighbors: backward through the graph a second time (saved tensors were freed)");
+        const at::Tensor* saved[6] = {&f, &tr, &q, &k, &fr, &dist};
+        for (int x = 0; x < 6; ++x)
+            if (saved[x]->_version() != versions[x])
+                throw std::runtime_error("one of the tensors handed to aggregate_neighbors() has been modified in place before its backward");
+        if (grads.empty() || !grads[0].defined()) return torch::autograd::variable_list(6);
+        at::AutoGradMode no_grad(false);
+        if (grads[0].requires_grad()) throw std::runtime_error("aggregate_neighbors is differentiable once");
+        const at::Tensor gout = grads[0].to(f.scalar_type()).contiguous();
+        at::Tensor g_f = at::empty_like(f), g_tr = at::empty_like(tr), g_q = at::empty_like(q), g_k = at::empty_like(k),
+                   g_fr = at::empty_like(fr), g_dist = at::empty_like(dist);
+        const int dt = dtype_code(f);
+        if (N > 0) {
+            const size_t nbytes = pigs_aggregate_backward_scratch_bytes(dt, N, L, F);
+            at::Tensor scratch = at::empty({(int64_t)nbytes}, f.options().dtype(at::kByte));
+            c10::DeviceGuard guard(f.device());
+            check(pigs_aggregate_backward(dt, N, nb->cap, L, K, F, ptr(nb->means), ptr(nb->conics), (const int32_t*)ptr(nb->row_counts),
+                                          (const int32_t*)ptr(nb->row_lists), (const int32_t*)ptr(nb->col_counts),
+                                          (const int32_t*)ptr(nb->col_lists), ptr(f), ptr(tr), ptr(q), ptr(k), ptr(fr), ptr(dist),
+                                          ptr(lse), ptr(acc), ptr(gout), scratch.data_ptr(), nbytes, ptr(g_f), ptr(g_tr), ptr(g_q),
+                                          ptr(g_k), ptr(g_fr), ptr(g_dist), current_stream(f)),
+                  "pigs_aggregate_backward");
+        } else {
+            g_tr.zero_(); g_fr.zero_(); g_dist.zero_();
+        }
+        return {g_f.to(in_dtypes[0]), g_tr.to(in_dtypes[1]), g_q.to(in_dtypes[2]), g_k.to(in_dtypes[3]), g_fr.to(in_dtypes[4]),
+                g_dist.to(in_dtypes[5])};
+    }
+    void release_variables() override {
+        f = tr = q = k = fr = dist = lse = acc = at::Tensor();
+    }
+};
+
+at::Tensor aggregate_apply(const std::shared_ptr<NeighborLists>& nb, const at::Tensor& features, const at::Tensor& transform,
+                           const at::Tensor& queries, const at::Tensor& keys, const at::Tensor& frequencies,
+                           const at::Tensor& distance_transform) {
+    const int64_t N = nb->N;
+    if (features.dim() != 2 || features.size(0) != N)
+        raise_py(PyExc_ValueError, "features must be [N=" + std::to_string(N) + ", L], got " + shape_str(features));
+    if (queries.dim() != 2 || keys.dim() != 2 || frequencies.dim() != 1 || transform.dim() != 2 || distance_transform.dim() != 2)
+        raise_py(PyExc_ValueError, "aggregate_neighbors: transform, queries, keys, distance_transform must be 2-d, frequencies 1-d");
+    const int64_t L = features.size(1), K = queries.size(1), F = frequencies.size(0), E = 4 * F + 1;
+    if (transform.size(0) != L || transform.size(1) != L || queries.size(0) != N || keys.size(0) != N || keys.size(1) != K ||
+        distance_transform.size(0) != L || distance_transform.size(1) != 2 * E)
+        raise_py(PyExc_ValueError, "aggregate_neighbors: expected transform [" + std::to_string(L) + "," + std::to_string(L) +
+                                       "], queries/keys [" + std::to_string(N) + "," + std::to_string(K) + "], distance_transform [" +
+                                       std::to_string(L) + "," + std::to_string(2 * E) + "] (E = 2*d*F + 1 = " + std::to_string(E) + ")");
+    const at::Tensor* ins[6] = {&features, &transform, &queries, &keys, &frequencies, &distance_transform};
+    const char* names[6] = {"features", "transform", "queries", "keys", "frequencies", "distance_transform"};
+    for (int x = 0; x < 6; ++x)
+        if (!ins[x]->is_cuda())
+            raise_py(PyExc_RuntimeError, std::string(names[x]) + " is on " + ins[x]->device().str() +
+                                             ": aggregate_neighbors runs on the GPU only (no CPU fallback)");
+    if (L + 2 * E > 128) raise_py(PyExc_NotImplementedError, "L + 2E = " + std::to_string(L + 2 * E) + " > 128 is not supported");
+    const auto dt = nb->means.scalar_type();
+    at::Tensor c[6];
+    {
+        at::AutoGradMode no_grad(false);
+        for (int x = 0; x < 6; ++x) c[x] = ins[x]->detach().to(dt).contiguous();
+    }
+    const auto opt = c[0].options();
+    at::Tensor out = at::empty({N, L}, opt), lse = at::empty({N}, opt), acc = at::empty({N, L + 2 * E}, opt);
+    if (N > 0) {
+        c10::DeviceGuard guard(c[0].device());
+        check(pigs_aggregate_forward(dtype_code(c[0]), N, nb->cap, (int)L, (int)K, (int)F, ptr(nb->means), ptr(nb->conics),
+                                     (const int32_t*)ptr(nb->row_counts), (const int32_t*)ptr(nb->row_lists), ptr(c[0]), ptr(c[1]),
+                                     ptr(c[2]), ptr(c[3]), ptr(c[4]), ptr(c[5]), ptr(out), ptr(lse), ptr(acc), current_stream(c[0])),
+              "pigs_aggregate_forward");
+    }
+    if (out.scalar_type() != features.scalar_type()) out = out.to(features.scalar_type());
+    bool need = false;
+    for (int x = 0; x < 6; ++x) need = need || ins[x]->requires_grad();
+    if (at::GradMode::is_enabled() && need) {
+        std::shared_ptr<AggregateBackward> node(new AggregateBackward(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(features, transform, queries, keys, frequencies, distance_transform));
+        node->nb = nb;
+        node->f = c[0]; node->tr = c[1]; node->q = c[2]; node->k = c[3]; node->fr = c[4]; node->dist = c[5];
+        node->lse = lse; node->acc = acc;
+        for (int x = 0; x < 6; ++x) { node->versions[x] = c[x]._version(); node->in_dtypes[x] = ins[x]->scalar_type(); }
+        node->N = N; node->L = (int)L; node->K = (int)K; node->F = (int)F;
+        torch::autograd::create_gradient_edge(out, node);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // the state behind GaussianSampler
 // ---------------------------------------------------------------------------------------------
 enum { FUSE_AUTO = 0, FUSE_ALL = 1, FUSE_NONE = 2 };
@@ -344,6 +494,7 @@ struct Core {
     std::vector<std::shared_ptr<SamplePlan>> sample_plans;      // most recently used first
     std::shared_ptr<PlanPool> pool = std::make_shared<PlanPool>();
     Outs cache;
+    std::shared_ptr<NeighborLists> neighbors;
     static bool warned_samples_grad;
 
     Core(bool debug_, int fuse_, int backend_, double q_max_, double q_max3_, double q_max_b_, int reuse_)
@@ -409,6 +560,7 @@ struct Core {
         for (auto& t : cache) t = at::Tensor();
         plan.reset();
         plan3.reset();
+        neighbors.reset();
         const bool use_plan = backend == BACKEND_BINNED || (backend == BACKEND_AUTO && N * samples.size(0) >= BINNED_AUTO_MIN_PAIRS);
         if (use_plan && plan_supported(means, values, samples))
             plan = make_plan(q_max, nullptr);
@@ -494,6 +646,19 @@ struct Core {
         return res;
     }
 
+    void preprocess_aggregate(int64_t cap) {
+        require_inputs();
+        if (means.size(1) != 2) raise_py(PyExc_NotImplementedError, "aggregate_neighbors is implemented for d = 2");
+        neighbors = std::make_shared<NeighborLists>(means, conics, (double)q_max, cap);
+        if (debug) neighbors->check_overflow();
+    }
+
+    at::Tensor aggregate_neighbors(const at::Tensor& features, const at::Tensor& transform, const at::Tensor& queries,
+                                   const at::Tensor& keys, const at::Tensor& frequencies, const at::Tensor& distance_transform) {
+        if (!neighbors) raise_py(PyExc_RuntimeError, "preprocess_aggregate() must be called before aggregate_neighbors()");
+        return aggregate_apply(neighbors, features, transform, queries, keys, frequencies, distance_transform);
+    }
+
     py::object inputs() const {
         if (!bound) return py::none();
         return py::make_tuple(means, values, conics, samples);
@@ -562,6 +727,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
             return error_flag(p.samples->workspace, pigs_samples_error_offset()) != 0 ||
                    error_flag(p.workspace, pigs_plan_error_offset()) != 0;
         });
+    py::class_<NeighborLists, std::shared_ptr<NeighborLists>>(m, "NeighborLists")
+        .def_readonly("N", &NeighborLists::N)
+        .def_readonly("cap", &NeighborLists::cap)
+        .def_readonly("row_counts", &NeighborLists::row_counts)
+        .def_readonly("col_counts", &NeighborLists::col_counts)
+        .def_readonly("row_lists", &NeighborLists::row_lists)
+        .def_readonly("col_lists", &NeighborLists::col_lists)
+        .def_readonly("overflow", &NeighborLists::overflow)
+        .def("check", &NeighborLists::check_overflow);
     py::class_<Core>(m, "SamplerCore")
         .def(py::init<bool, int, int, double, double, double, int>(), py::arg("debug"), py::arg("fuse"), py::arg("backend"),
              py::arg("q_max"), py::arg("q_max_order3"), py::arg("q_max_backward"), py::arg("reuse_samples"))
@@ -569,6 +743,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("get", &Core::get)
         .def("sample", &Core::sample)
         .def("inputs", &Core::inputs)
+        .def("preprocess_aggregate", &Core::preprocess_aggregate, py::arg("cap") = -1)
+        .def("aggregate_neighbors", &Core::aggregate_neighbors)
+        .def_readonly("neighbors", &Core::neighbors)
         .def_readonly("plan", &Core::plan)
         .def_readonly("plan3", &Core::plan3)
         .def_property_readonly("sample_plans", [](const Core& c) { return c.sample_plans; })

@@ -390,6 +390,11 @@ class GaussianSampler:
     follow this repository's own definition (the reference's is not visible: parity unpinned) and
     warn once per process unless this is set.
 
+    ``aggregate_cap`` (extension, keyword only): slots per Gaussian of the neighbour lists of
+    ``preprocess_aggregate``.  Default ``None``: sized by a counting pass whose result is read back once per
+    call (a host synchronisation); an integer skips that (lists that do not fit are truncated and flagged:
+    debug mode raises).
+
     ``fuse`` (extension, keyword only) controls how many derivative orders one launch computes:
     ``"auto"`` -- the first ``sample_*`` call after a ``preprocess`` computes orders 0..2 in one
     launch when the problem is small enough to be launch-bound (M <= 65536), otherwise only the
@@ -417,7 +422,7 @@ class GaussianSampler:
     _warned_aggregate = False
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
-                 q_max_backward=None, reuse_samples=True, unpinned_aggregate=False, host=None):
+                 q_max_backward=None, reuse_samples=True, unpinned_aggregate=False, aggregate_cap=None, host=None):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):
@@ -441,6 +446,7 @@ class GaussianSampler:
             raise ValueError("q_max_backward must not be below q_max")
         self.reuse_samples = 4 if reuse_samples is True else max(0, int(reuse_samples))
         self.unpinned_aggregate = bool(unpinned_aggregate)
+        self.aggregate_cap = None if aggregate_cap is None else int(aggregate_cap)
         self._neighbors = None
         self._st_plan3 = None
         self._st_inputs = None
@@ -659,16 +665,22 @@ class GaussianSampler:
                           "repository's own definition (pigs_amd/aggregate.py, DESIGN.md) -- a model trained with "
                           "the reference will not reproduce through it.  Pass unpinned_aggregate=True to "
                           "GaussianSampler to acknowledge.", stacklevel=2)
+        if self._core is not None:
+            self._core.preprocess_aggregate(-1 if self.aggregate_cap is None else self.aggregate_cap)
+            self._neighbors = self._core.neighbors
+            return
         means, _, conics, _ = self._require_inputs()
         if means.shape[1] != 2:
             raise NotImplementedError("aggregate_neighbors is implemented for d = 2")
-        self._neighbors = aggregate.NeighborLists(means, conics, self.q_max)
+        self._neighbors = aggregate.NeighborLists(means, conics, self.q_max, cap=self.aggregate_cap)
         if self.debug:
             self._neighbors.check()
 
     def aggregate_neighbors(self, features, transform, queries, keys, frequencies, distance_transform):
         """[N, L] attention-weighted neighbour messages (model_pn.py:262-264); differentiable wrt all
         six arguments (test_neighbor_aggregation.py:89-98).  Parity unpinned: pigs_amd/aggregate.py."""
+        if self._core is not None:
+            return self._core.aggregate_neighbors(features, transform, queries, keys, frequencies, distance_transform)
         from . import aggregate
         if self._neighbors is None:
             raise RuntimeError("preprocess_aggregate() must be called before aggregate_neighbors()")

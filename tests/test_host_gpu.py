@@ -195,3 +195,35 @@ def test_plan_used_on_another_stream_is_not_recycled(hip_lib):
                 s.sample_gaussians()
             torch.cuda.synchronize()
         assert plan.other_stream_used
+
+
+@pytest.mark.parametrize("N", [300, 3000])
+def test_hosts_agree_on_aggregate_neighbors(hip_lib, N):
+    """preprocess_aggregate / aggregate_neighbors (parity unpinned: this repository's own definition) through
+    both hosts: N = 300 takes the all-pairs list build, N = 3000 the grid build with its counting pass."""
+    from diff_gaussian_sampling import GaussianSampler
+    rng = np.random.default_rng(N)
+    side = int(np.sqrt(N))
+    gs = synthetic.lattice_gaussians(side, N // side, 1.1, seed=N)
+    n = gs["means"].shape[0]
+    means, conics, values = (gs[k].float().cuda() for k in ("means", "conics", "values"))
+    L, K, F = 8, 4, 3
+    E = 4 * F + 1
+    gen = torch.Generator().manual_seed(2)
+    mk = lambda *s: torch.randn(*s, generator=gen).cuda().requires_grad_(True)
+    args = [mk(n, L), mk(L, L), mk(n, K), mk(n, K), mk(F), mk(L, 2 * E)]
+    gout = torch.randn((n, L), generator=gen).cuda()
+    res = {}
+    for host in HOSTS:
+        s = GaussianSampler(True, unpinned_aggregate=True, host=host)
+        s.preprocess(means, values, None, conics, means)
+        s.preprocess_aggregate()
+        out = s.aggregate_neighbors(*args)
+        res[host] = [out.detach()] + list(torch.autograd.grad(out, args, grad_outputs=gout))
+        nb = s._neighbors
+        assert int(nb.overflow.item()) == 0 and int(nb.row_counts.max()) <= nb.cap
+        res[host + "_pairs"] = int(nb.row_counts.sum())
+        assert int(nb.col_counts.sum()) == res[host + "_pairs"]
+    assert res["native_pairs"] == res["ctypes_pairs"]
+    for a, b in zip(res["native"], res["ctypes"]):
+        assert rel(a, b) < 2e-5

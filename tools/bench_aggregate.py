@@ -35,6 +35,9 @@ for dtype in (torch.float32, torch.float64):
         s.preprocess(means, values, None, conics, means)
         t_lists = timed(s.preprocess_aggregate)
         nb = s._neighbors
+        s2 = GaussianSampler(False, unpinned_aggregate=True, aggregate_cap=nb.cap)      # slab size given: one pass, no read-back
+        s2.preprocess(means, values, None, conics, means)
+        t_lists_cap = timed(s2.preprocess_aggregate)
         pairs = int(nb.row_counts.sum())
         with torch.no_grad():
             t_fwd = timed(lambda: s.aggregate_neighbors(*args))
@@ -44,5 +47,5 @@ for dtype in (torch.float32, torch.float64):
             out = s.aggregate_neighbors(*args)
             torch.autograd.grad(out, args, grad_outputs=gout)
         t_fb = timed(fb)
-        print(f"{str(dtype)[6:]:8s} N={N:6d} kappa={kappa}: {pairs / N:6.1f} neighbours per Gaussian | lists {t_lists:7.1f} us | "
+        print(f"{str(dtype)[6:]:8s} N={N:6d} kappa={kappa}: {pairs / N:6.1f} neighbours per Gaussian (cap {nb.cap}) | lists {t_lists:7.1f} us (cap given: {t_lists_cap:7.1f}) | "
               f"forward {t_fwd:7.1f} us | forward + backward (all six gradients) {t_fb:7.1f} us", flush=True)
