@@ -46,6 +46,7 @@
 namespace pigs {
 
 constexpr int PLAN_MAX_LEVELS = 12;
+constexpr int PLAN_BAR_WORDS = 2 * 17 + 1;   // two barriers of 17 words + the exit counter (plan.hip, grid_barrier)
 constexpr uint32_t PLAN_SCAN_BLOCK = 256 * 4;     // counters scanned per workgroup (one uint4 per thread)
 
 constexpr int TILE_POINTS = 64;            // one wave
@@ -104,6 +105,7 @@ struct PlanParams {
                                                // the traversal indexes it by lane)
     uint32_t scan_error;
     float q_f, q_b;        // the plan's two cut-offs (forward / backward of order >= 2 gradients), q_b >= q_f
+    uint32_t bar[PLAN_BAR_WORDS];   // device-wide barriers of the one-launch Gaussian chain (zero between builds)
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -29,6 +29,13 @@
 #ifndef PIGS_FWD_UNROLL
 #define PIGS_FWD_UNROLL 2     // list rows evaluated per loop iteration
 #endif
+#ifndef PIGS_FUSED_BUILD
+#define PIGS_FUSED_BUILD 0    // 1: count + scan + scatter of the Gaussians in ONE launch when the samples half is reused
+                              // (plan_gauss_build_kernel).  Measured SLOWER than the three launches it replaces: warm step
+                              // 59.4 us with three launches, 80.4 with release / acquire barriers, 66.3 with relaxed barriers
+                              // + L2-bypassing accesses, 70.4 with per-XCD arrival counters -- a device-wide barrier on 8
+                              // mutually incoherent L2s costs more than the ~3.7 us of a kernel boundary.  Kept as the record.
+#endif
 #ifndef PIGS_BWD_WAVES
 #define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to (its LDS allows 4 workgroups per CU)
 #endif
@@ -84,7 +91,10 @@ __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
 __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     __shared__ float sh[4][4];
     zero_words(a.scounts, a.s_zero_words);
-    if (a.do_plan) zero_words(a.counts, a.zero_words);
+    if (a.do_plan) {
+        zero_words(a.counts, a.zero_words);
+        if (blockIdx.x == 0 && threadIdx.x < PLAN_BAR_WORDS) a.params->bar[threadIdx.x] = 0u;
+    }
     const float INF = __builtin_huge_valf();
     float x0 = INF, y0 = INF, x1 = -INF, y1 = -INF;
     auto take = [&](float x, float y) {
@@ -123,7 +133,10 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
 
 // a plan built on an existing samples workspace has no bbox launch in front of it: its counters
 // are zeroed by this one
-__global__ __launch_bounds__(256) void plan_zero_kernel(BuildArgs a) { zero_words(a.counts, a.zero_words); }
+__global__ __launch_bounds__(256) void plan_zero_kernel(BuildArgs a) {
+    zero_words(a.counts, a.zero_words);
+    if (blockIdx.x == 0 && threadIdx.x < PLAN_BAR_WORDS) a.params->bar[threadIdx.x] = 0u;
+}
 
 // every workgroup of the count kernel reduces the PLAN_BBOX_BLOCKS partials (4 KB, L2 resident)
 __device__ __forceinline__ void reduce_boxes(const float4* boxes, float* sbox, float (*sh)[4]) {
@@ -280,19 +293,31 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
 // only records that this happened (a diagnostic; never seen with in-order dispatch).
 // `no_lookback` (PIGS_BUILD_DEBUG_NO_LOOKBACK) makes every thread take that path: the test hook.
 constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 14;
-__global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
-    __shared__ uint32_t sh[4];
-    __shared__ uint32_t sh2[4];
-    const uint32_t nb0 = a.do_plan ? a.scan_blocks : 0;
-    const bool seg0 = blockIdx.x < nb0;
-    const uint32_t b = seg0 ? blockIdx.x : blockIdx.x - nb0;
+// COH: counters read and starts written with agent-scope accesses that bypass the (per-XCD, mutually
+// incoherent) L2s -- for the one-launch chain, where producer and consumer phases of one launch run on
+// different XCDs with no kernel boundary in between.
+template <bool COH>
+__device__ __forceinline__ uint4 scan_load4(const uint32_t* p) {
+    if constexpr (COH) {
+        uint4 v;
+        v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    } else {
+        return *(const uint4*)p;
+    }
+}
+template <bool COH>
+__device__ __forceinline__ void scan_block(const BuildArgs& a, bool seg0, uint32_t b, uint32_t* sh, uint32_t* sh2) {
     const uint32_t* counts = seg0 ? a.counts : a.scounts;
     unsigned long long* agg = seg0 ? a.agg : a.sagg;
     uint32_t* starts = seg0 ? a.starts : a.sstarts;
     uint32_t* err = seg0 ? &a.params->scan_error : &a.sparams->scan_error;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t q = b * 256 + threadIdx.x;          // uint4 index
-    const uint4 v = ((const uint4*)counts)[q];
+    const uint4 v = scan_load4<COH>(counts + 4 * (size_t)q);
     const uint32_t s = v.x + v.y + v.z + v.w;
     uint32_t inc = s;
 #pragma unroll
@@ -316,10 +341,10 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
             }
         }
         if (!(x >> 32)) {       // not published (in time): workgroup t's total from its counters
-            const uint4* c4 = (const uint4*)counts + (size_t)t * 256;
+            const uint32_t* c4 = counts + (size_t)t * 1024;
             uint32_t tot = 0;
             for (int i = 0; i < 256; ++i) {
-                const uint4 w = c4[i];
+                const uint4 w = scan_load4<COH>(c4 + 4 * i);
                 tot += w.x + w.y + w.z + w.w;
             }
             x = tot;
@@ -335,7 +360,23 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     for (int w = 0; w < wave; ++w) run += sh[w];
     uint4 o4;
     o4.x = run; o4.y = run + v.x; o4.z = o4.y + v.y; o4.w = o4.z + v.z;
-    ((uint4*)starts)[q] = o4;      // counters beyond the last cell are zero: starts[ncells] = total
+    // counters beyond the last cell are zero: starts[ncells] = total
+    if constexpr (COH) {
+        uint32_t* d = starts + 4 * (size_t)q;
+        __hip_atomic_store(d + 0, o4.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 1, o4.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 2, o4.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 3, o4.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        ((uint4*)starts)[q] = o4;
+    }
+}
+__global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
+    __shared__ uint32_t sh[4];
+    __shared__ uint32_t sh2[4];
+    const uint32_t nb0 = a.do_plan ? a.scan_blocks : 0;
+    const bool seg0 = blockIdx.x < nb0;
+    scan_block<false>(a, seg0, seg0 ? blockIdx.x : blockIdx.x - nb0, sh, sh2);
 }
 
 // Launch 4: scatter into sorted order (no atomics: position = cell start + rank) and publish the
@@ -389,6 +430,129 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         SPoint sp;
         sp.x = p.x; sp.y = p.y; sp.m = i;
         a.spts[a.sstarts[kr.x] + kr.y] = sp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The Gaussian chain count -> scan -> scatter in ONE launch (a build on an existing samples workspace: the
+// warm path, main_pn.py:317-324).  Each of the three launches it replaces sits at the floor of a dependent
+// launch on this chip (~3.7 us: every kernel boundary is an L2 write-back and invalidate across 8 XCDs)
+// while doing ~1 us of work; here the phases are separated by two device-wide barriers instead, and a
+// Gaussian's {cell, rank} stays in its thread's registers between count and scatter.
+// The barriers need every workgroup resident at once: the grid is ceil(N / 256) workgroups of 256 threads
+// with a few hundred bytes of LDS (2 048 fit the chip), and the host uses this kernel only up to
+// FUSED_BUILD_MAX_BLOCKS workgroups -- several such builds on different streams still fit side by side;
+// larger N keep the three launches.  What one phase hands to the next across XCDs (the counters, starts[])
+// travels through agent-scope accesses that bypass the per-XCD L2s; the barrier itself is a relaxed counter
+// behind a workgroup-scope fence (a release / acquire pair at agent scope writes back and invalidates the
+// whole L2 once per workgroup and barrier: measured +21 us over the three launches it was to replace).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t FUSED_BUILD_MAX_BLOCKS = 256;
+// One barrier = 17 words: arrivals are counted per XCD-sized group of workgroups (id & 7: 32 arrivals per
+// address instead of 256 -- same-address atomics retire one every ~10 ns), the last arrival of a group
+// counts the group in, the last group raises eight release flags and every workgroup polls its own group's
+// (32 pollers per address).
+constexpr int BAR_WORDS = 17;
+__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t G) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's memory operations have completed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t grp = blockIdx.x & 7u;
+        const uint32_t in_grp = (G - grp + 7u) >> 3, groups = G < 8u ? G : 8u;
+        if (__hip_atomic_fetch_add(&bar[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1u) {
+            if (__hip_atomic_fetch_add(&bar[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) __hip_atomic_store(&bar[9 + k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        while (__hip_atomic_load(&bar[9 + grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
+    __shared__ uint32_t sh[4];
+    __shared__ uint32_t sh2[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < a.N;
+    float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    if (valid) {
+        mx = a.means[2 * i]; my = a.means[2 * i + 1];
+        ca = a.conics[3 * i]; cb = a.conics[3 * i + 1]; cc = a.conics[3 * i + 2];
+    }
+    float sbox[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sbox[k] = a.sparams->box[k];
+    const GaussGrid g = gauss_grid(sbox, a.G0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.params->gg = g;
+        a.params->scan_error = 0;
+        a.params->q_f = a.q_f;
+        a.params->q_b = a.q_b;
+#pragma unroll
+        for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
+    }
+    // ---- count: cell key and rank (plan_count_kernel's Gaussian half)
+    uint32_t key = 0xffffffffu;
+    const float det = ca * cc - cb * cb;
+    if (valid) {
+        const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
+        float s = g.s0;
+        int l = 0;
+        while (l < a.L - 1 && !(R <= s)) { ++l; s *= 2.f; }
+        const int G = a.G0 >> l;
+        const float inv_s = 1.f / s;
+        const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
+        const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
+        key = a.level_off[l] + ((uint32_t)(cy * G + cx) << level_shift((uint32_t)(G * G)));
+    }
+    const Run r = run_of(key, lane);
+    uint32_t base = 0;
+    if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
+    base = __shfl(base, r.start);
+    const uint32_t rank = base + (uint32_t)(lane - r.start);
+    grid_barrier(&a.params->bar[0], gridDim.x);
+    // ---- scan (the first scan_blocks workgroups; their look-back is among resident workgroups)
+    if (blockIdx.x < a.scan_blocks) scan_block<true>(a, true, blockIdx.x, sh, sh2);
+    grid_barrier(&a.params->bar[BAR_WORDS], gridDim.x);
+    // ---- scatter (plan_scatter_kernel's Gaussian half)
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const int l = (int)threadIdx.x;
+        const int lc = l < a.L ? l : 0;
+        const bool occ = l < a.L && __hip_atomic_load(&a.starts[a.level_off[lc + 1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+                                        __hip_atomic_load(&a.starts[a.level_off[lc]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t m = __ballot(occ);
+        if (threadIdx.x == 0) a.params->level_mask = (uint32_t)m;
+    }
+    // the scan has consumed the counters and its own flags: leave them zeroed (PIGS_BUILD_PLAN_WS_CLEAN)
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.zero_words; k += gridDim.x * 256) a.counts[k] = 0u;
+    if (valid) {
+        const uint32_t pos = __hip_atomic_load(&a.starts[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + rank;
+        float v[2] = {0.f, 0.f};
+        for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
+        a.rec[2 * pos] = make_float4(mx, my, ca, cb);
+        a.rec[2 * pos + 1] = make_float4(cc, v[0], v[1], 0.f);
+        if (i == 0) {
+            a.rec[2 * (size_t)a.N] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a.rec[2 * (size_t)a.N + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float k = a.q_max / det;
+        float hx = sqrtf(k * cc), hy = sqrtf(k * ca);
+        if (!(hx < 3.0e38f)) hx = 3.0e38f;      // NaN / inf (degenerate conic): always a candidate
+        if (!(hy < 3.0e38f)) hy = 3.0e38f;
+        a.gbox[pos] = make_float4(mx, my, hx * 1.0001f, hy * 1.0001f);
+        a.g2o[pos] = i;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a.gacc[(size_t)q * a.N + pos] = 0.f;
+    }
+    // ---- the last workgroup out re-arms the barriers for the next build into this workspace
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(&a.params->bar[2 * BAR_WORDS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            for (int q = 0; q < PLAN_BAR_WORDS; ++q) __hip_atomic_store(&a.params->bar[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1427,12 +1591,17 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
     if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
     else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 1023) / 1024) : 0u)), dim3(256), 0,
-                       stream, a);
-    hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? s.scan_blocks : 0u)),
-                       dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 255) / 256) : 0u)), dim3(256), 0,
-                       stream, a);
+    const uint32_t fused_blocks = gb > p.scan_blocks ? gb : p.scan_blocks;
+    if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {
+        hipLaunchKernelGGL(plan_gauss_build_kernel, dim3(fused_blocks), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 1023) / 1024) : 0u)), dim3(256), 0,
+                           stream, a);
+        hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? s.scan_blocks : 0u)),
+                           dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 255) / 256) : 0u)), dim3(256), 0,
+                           stream, a);
+    }
     if (do_plan && build_lists) {
         ListArgs la{};
         la.pv = make_view(p, ws, a.q_max);
