@@ -130,8 +130,13 @@ def graph_replay(GaussianSampler, t, pts_d, backend, n):
             loss = ((u - lap) ** 2).mean() + (ux ** 2).mean()
             return torch.autograd.grad(loss, list(req.values()))
 
+        def residual_step():
+            sampler.preprocess(req["means"], req["values"], t["covariances"], req["conics"], pts_d)
+            loss = sampler.residual(a0=1.0, lap=-1.0).pow(2).mean()
+            return torch.autograd.grad(loss, list(req.values()))
+
         for name, fn in (("ms_per_step", train_step), ("sampler_only_ms_per_step", sampler_step),
-                         ("trace_residual_ms_per_step", trace_step)):
+                         ("trace_residual_ms_per_step", trace_step), ("fused_residual_ms_per_step", residual_step)):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize(dev)
@@ -461,6 +466,14 @@ def main():
             loss = ((u - lap) ** 2).mean() + (ux ** 2).mean()
             return torch.autograd.grad(loss, list(req.values()))
 
+        def residual_step():
+            # the diffusion residual of test_no_mlp.py:144 (u_t replaced by u) in ONE forward launch (4 B per point
+            # out) and one backward launch: sampler.residual() -- extension of the reference API, SURVEY.md 8f-4
+            m_r, v_r, c_r = replicated(req["means"], req["values"], req["conics"])
+            sampler_w.preprocess(m_r, v_r, t["covariances"], c_r, pts_d)
+            loss = sampler_w.residual(a0=1.0, lap=-1.0).pow(2).mean()
+            return torch.autograd.grad(loss, list(req.values()))
+
         nb = max(1, min(a.steps, 100))
         wb = min(10, nb)        # eager steps settle after a few iterations (caching allocator, autograd graph reuse)
         sampler_only_s = timed_steps(sampler_step, wb, nb) / nb
@@ -468,7 +481,8 @@ def main():
         fwd_bwd = {"ms_per_step": timed_steps(train_step, wb, nb) / nb * 1e3,
                    "sampler_only_ms_per_step": sampler_only_s * 1e3,
                    "sampler_only_host_issue_ms_per_step": host_sampler_only * 1e3,
-                   "trace_residual_ms_per_step": timed_steps(trace_step, wb, nb) / nb * 1e3, "steps": nb,
+                   "trace_residual_ms_per_step": timed_steps(trace_step, wb, nb) / nb * 1e3,
+                   "fused_residual_ms_per_step": timed_steps(residual_step, wb, nb) / nb * 1e3, "steps": nb,
                    "value": M * world / sampler_only_s,
                    "dist_backend": (dist.get_backend() if dist is not None else None), "world_size": world,
                    "what": "value: points/s of the sampler-only step = preprocess (samples half reused) + fused fwd(0..2) "
@@ -477,7 +491,9 @@ def main():
                               if dist is not None else "")
                            + "; ms_per_step: the same with a torch residual loss; trace_residual: the training step "
                            "with the fused u, grad u, u_xx+u_yy outputs (sample((0, 1, 'lap'))) instead of the full "
-                           "Hessian; hipgraph_replay (1 GPU): the same steps captured once and replayed"}
+                           "Hessian; fused_residual: the training step of the residual u - lap u through "
+                           "sampler.residual() (one forward launch writing 4 B per point, one backward launch, the loss "
+                           "one pow + mean); hipgraph_replay (1 GPU): the same steps captured once and replayed"}
         # backward kernel alone
         means, values, conics, samples = sampler_w._inputs
         plan = sampler_w._plan

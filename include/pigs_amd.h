@@ -152,6 +152,26 @@ int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samp
                        const void* gout0, const void* gout1, const void* gout2, const void* gout3,
                        void* g_means, void* g_conics, void* g_values, void* stream);
 
+/*
+ * Linear residual of the sampled field in ONE launch (extension): the diffusion / wave
+ * residuals of the reference's losses (model_pn.py:612-617, 834-849; test_no_mlp.py:127-144) are
+ *     r[m][c] = a0 u + a1x du/dx + a1y du/dy + aL (u_xx + u_yy) - target[m][c]
+ * with constant coefficients `coeffs` = {a0, a1x, a1y, aL} (HOST doubles) and an optional `target`
+ * [M][c] (device; e.g. u_prev / dt): 4 bytes per point and channel leave the kernel instead of the 28 of
+ * u, grad u and the Hessian, and the loss is one elementwise + reduction on r.  The backward takes the
+ * gradient gout [M][c] that arrives at r and returns the gradients wrt means, conics, values (the three
+ * buffers are overwritten; d r / d target = -1 is the caller's).  plan_ws == NULL: dense (d in {1,2},
+ * f32 / f64); else through a built plan (d = 2, f32; backward with the plan's wide cut-off).
+ */
+int pigs_residual_forward(int dtype, int d, int c, int64_t N, int64_t M,
+                          const void* means, const void* conics, const void* values, const void* samples,
+                          const double coeffs[4], const void* target, void* out,
+                          void* plan_ws, size_t plan_ws_bytes, const void* samples_ws, size_t samples_ws_bytes, void* stream);
+int pigs_residual_backward(int dtype, int d, int c, int64_t N, int64_t M,
+                           const void* means, const void* conics, const void* values, const void* samples,
+                           const double coeffs[4], const void* gout, void* g_means, void* g_conics, void* g_values,
+                           void* plan_ws, size_t plan_ws_bytes, const void* samples_ws, size_t samples_ws_bytes, void* stream);
+
 /* Byte offset, inside a samples / plan workspace, of a uint32 DIAGNOSTIC that a build leaves at 0 and
  * sets to non-zero when a workgroup of its in-kernel scan did not receive a predecessor's total within
  * the bounded wait and summed that predecessor's counters itself.  The result is valid either way

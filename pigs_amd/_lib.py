@@ -42,6 +42,10 @@ SIGNATURES = {
                           + [_vp] * 4 + [_vp]),
     "pigs_plan_backward": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i]
                            + [_vp] * 4 + [_vp] * 3 + [_vp]),
+    "pigs_residual_forward": (_i, [_i, _i, _i, _i64, _i64] + [_vp] * 4 + [ctypes.POINTER(ctypes.c_double), _vp, _vp]
+                              + [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+    "pigs_residual_backward": (_i, [_i, _i, _i, _i64, _i64] + [_vp] * 4 + [ctypes.POINTER(ctypes.c_double), _vp] + [_vp] * 3
+                               + [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     "pigs_aggregate_workspace_bytes": (ctypes.c_size_t, [_i, _i64]),
     "pigs_aggregate_lists": (_i, [_i, _i64, _i64, _vp, _vp, ctypes.c_double, _vp, ctypes.c_size_t, _i] + [_vp] * 5 + [_vp]),
     "pigs_aggregate_forward": (_i, [_i, _i64, _i64, _i, _i, _i] + [_vp] * 4 + [_vp] * 6 + [_vp] * 3 + [_vp]),

@@ -132,6 +132,50 @@ int pigs_plan_backward(void* workspace, size_t workspace_bytes, const void* samp
                          g_means, g_conics, g_values, (hipStream_t)stream);
 }
 
+// ---- linear residual (pair_math.h ORDR): dense when plan_ws is null, else through the plan
+int pigs_residual_forward(int dtype, int d, int c, int64_t N, int64_t M, const void* means, const void* conics,
+                          const void* values, const void* samples, const double* coeffs, const void* target, void* out,
+                          void* plan_ws, size_t plan_ws_bytes, const void* samples_ws, size_t samples_ws_bytes, void* stream) {
+    if (!coeffs || (M > 0 && !out)) return PIGS_ERR_INVALID;
+    if (plan_ws) {
+        if (dtype != PIGS_F32 || d != 2) return PIGS_ERR_UNSUPPORTED;
+        void* outs[4] = {out, nullptr, nullptr, nullptr};
+        return plan_forward(plan_ws, plan_ws_bytes, samples_ws, samples_ws_bytes, N, M, c, 0.f, 32, outs, (hipStream_t)stream,
+                            coeffs, target);
+    }
+    int rc = check_common(dtype, d, c, 1, N, M, means, conics, values, samples);
+    if (rc != PIGS_OK) return rc;
+    SampleArgs a{};
+    a.dtype = dtype; a.d = d; a.c = c; a.orders_mask = 32; a.N = N; a.M = M;
+    a.means = means; a.conics = conics; a.values = values; a.samples = samples;
+    a.out[0] = out;
+    for (int k = 0; k < 4; ++k) a.resid[k] = coeffs[k];
+    a.target = target;
+    return dense_dispatch(false, a, (hipStream_t)stream);
+}
+
+int pigs_residual_backward(int dtype, int d, int c, int64_t N, int64_t M, const void* means, const void* conics,
+                           const void* values, const void* samples, const double* coeffs, const void* gout, void* g_means,
+                           void* g_conics, void* g_values, void* plan_ws, size_t plan_ws_bytes, const void* samples_ws,
+                           size_t samples_ws_bytes, void* stream) {
+    if (!coeffs || (M > 0 && !gout) || (N > 0 && (!g_means || !g_conics || !g_values))) return PIGS_ERR_INVALID;
+    if (plan_ws) {
+        if (dtype != PIGS_F32 || d != 2) return PIGS_ERR_UNSUPPORTED;
+        const void* gs[4] = {gout, nullptr, nullptr, nullptr};
+        return plan_backward(plan_ws, plan_ws_bytes, samples_ws, samples_ws_bytes, N, M, c, 0.f, 32, gs, g_means, g_conics,
+                             g_values, (hipStream_t)stream, coeffs);
+    }
+    int rc = check_common(dtype, d, c, 1, N, M, means, conics, values, samples);
+    if (rc != PIGS_OK) return rc;
+    SampleArgs a{};
+    a.dtype = dtype; a.d = d; a.c = c; a.orders_mask = 32; a.N = N; a.M = M;
+    a.means = means; a.conics = conics; a.values = values; a.samples = samples;
+    a.gout[0] = gout;
+    a.g_means = g_means; a.g_conics = g_conics; a.g_values = g_values;
+    for (int k = 0; k < 4; ++k) a.resid[k] = coeffs[k];
+    return dense_dispatch(true, a, (hipStream_t)stream);
+}
+
 static int aggregate_sizes_ok(int dtype, int64_t N, int64_t cap, int L, int K, int F) {
     if (dtype != PIGS_F32 && dtype != PIGS_F64) return PIGS_ERR_UNSUPPORTED;
     if (N < 0 || cap < 1 || L < 1 || K < 1 || F < 0) return PIGS_ERR_INVALID;

@@ -22,7 +22,7 @@ template <typename T, int D, int C, int MASK, int NW>
 __global__ __launch_bounds__(NW * 64) void dense_forward_kernel(
     int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics,
     const T* __restrict__ values, const T* __restrict__ samples, T* __restrict__ o0, T* __restrict__ o1,
-    T* __restrict__ o2, T* __restrict__ o3) {
+    T* __restrict__ o2, T* __restrict__ o3, Resid<T> rz) {
     using L = FwdLayout<D, C, MASK>;
     constexpr int NF = Sym<D>::NF;
     __shared__ T red[(NW > 1 ? NW - 1 : 1) * L::N * 64];
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NW * 64) void dense_forward_kernel(
             for (int i = 0; i < C; ++i) v[u][i] = values[(n + u) * C + i];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) fwd_accumulate<T, D, C, MASK>(acc, s, mu[u], con[u], v[u]);
+        for (int u = 0; u < U; ++u) fwd_accumulate<T, D, C, MASK>(acc, s, mu[u], con[u], v[u], &rz);
     }
     for (int64_t m2 = n; m2 < N && m2 < n + U; ++m2) {          // ragged tail of this wave's last chunk
         T mu[D], con[NF], v[C];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NW * 64) void dense_forward_kernel(
         for (int i = 0; i < NF; ++i) con[i] = conics[m2 * NF + i];
 #pragma unroll
         for (int i = 0; i < C; ++i) v[i] = values[m2 * C + i];
-        fwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v);
+        fwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v, &rz);
     }
 
     if constexpr (NW > 1) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NW * 64) void dense_forward_kernel(
             }
         }
     }
-    if (wave == 0 && valid) fwd_store<T, D, C, MASK>(acc, m, o0, o1, o2, o3);
+    if (wave == 0 && valid) fwd_store<T, D, C, MASK>(acc, m, o0, o1, o2, o3, &rz);
 }
 
 template <typename T, int D, int C, int MASK, int NW>
@@ -90,8 +90,13 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
     int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics,
     const T* __restrict__ values, const T* __restrict__ samples, const T* __restrict__ G0,
     const T* __restrict__ G1, const T* __restrict__ G2, const T* __restrict__ G3, T* __restrict__ g_means,
-    T* __restrict__ g_conics, T* __restrict__ g_values) {
+    T* __restrict__ g_conics, T* __restrict__ g_values, Resid<T> rz) {
     using L = BwdLayout<D, C>;
+    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;      // a residual's backward = orders 0, 1, trace
+    auto load = [&](Gsym<T, D, C, EM>& G, int64_t m) {
+        if constexpr (MASK == ORDR) G.load_residual(m, G0, rz);
+        else G.load(m, G0, G1, G2, G3);
+    };
     constexpr int NF = Sym<D>::NF;
     __shared__ T red[(NW > 1 ? NW - 1 : 1) * L::N * 64];
 
@@ -124,19 +129,19 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
         T s0[D], s1[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) { s0[i] = samples[m * D + i]; s1[i] = samples[(m + 1) * D + i]; }
-        Gsym<T, D, C, MASK> Ga, Gb;
-        Ga.load(m, G0, G1, G2, G3);
-        Gb.load(m + 1, G0, G1, G2, G3);
-        bwd_accumulate<T, D, C, MASK, true>(acc, s0, mu, con, v, Ga);
-        bwd_accumulate<T, D, C, MASK, true>(acc, s1, mu, con, v, Gb);
+        Gsym<T, D, C, EM> Ga, Gb;
+        load(Ga, m);
+        load(Gb, m + 1);
+        bwd_accumulate<T, D, C, EM, true>(acc, s0, mu, con, v, Ga);
+        bwd_accumulate<T, D, C, EM, true>(acc, s1, mu, con, v, Gb);
     }
     if (m < m_end) {                       // odd point of this wave's last pair
         T s0[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) s0[i] = samples[m * D + i];
-        Gsym<T, D, C, MASK> Ga;
-        Ga.load(m, G0, G1, G2, G3);
-        bwd_accumulate<T, D, C, MASK, true>(acc, s0, mu, con, v, Ga);
+        Gsym<T, D, C, EM> Ga;
+        load(Ga, m);
+        bwd_accumulate<T, D, C, EM, true>(acc, s0, mu, con, v, Ga);
     }
 
     if constexpr (NW > 1) {
@@ -195,19 +200,20 @@ static int launch_dense_forward(const SampleArgs& a, hipStream_t stream) {
     const T* means = (const T*)a.means; const T* conics = (const T*)a.conics;
     const T* values = (const T*)a.values; const T* samples = (const T*)a.samples;
     T* o0 = (T*)a.out[0]; T* o1 = (T*)a.out[1]; T* o2 = (T*)a.out[2]; T* o3 = (T*)a.out[3];
+    const Resid<T> rz{(T)a.resid[0], {(T)a.resid[1], (T)a.resid[2]}, (T)a.resid[3], (const T*)a.target};
     constexpr int NACC = FwdLayout<D, C, MASK>::N;
     // few point blocks: spread the Gaussian loop over 16 waves per workgroup
     constexpr bool can16 = (15 * NACC * 64 * sizeof(T) <= 60 * 1024);
     if constexpr (can16) {
       if (blocks < 1024 && a.N >= 64) {
         hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream,
-                           a.N, a.M, means, conics, values, samples, o0, o1, o2, o3);
+                           a.N, a.M, means, conics, values, samples, o0, o1, o2, o3, rz);
         return launch_status();
       }
     }
     {
         hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 4>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                           a.N, a.M, means, conics, values, samples, o0, o1, o2, o3);
+                           a.N, a.M, means, conics, values, samples, o0, o1, o2, o3, rz);
     }
     return launch_status();
 }
@@ -245,7 +251,8 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((dense_backward_kernel<T, D, C, MASK, 4>), dim3((unsigned)gblocks, (unsigned)ysplit), dim3(256),
                        0, stream, a.N, a.M, (const T*)a.means, (const T*)a.conics, (const T*)a.values,
                        (const T*)a.samples, (const T*)a.gout[0], (const T*)a.gout[1], (const T*)a.gout[2],
-                       (const T*)a.gout[3], gm, gc, gv);
+                       (const T*)a.gout[3], gm, gc, gv,
+                       Resid<T>{(T)a.resid[0], {(T)a.resid[1], (T)a.resid[2]}, (T)a.resid[3], nullptr});
     return launch_status();
 }
 
@@ -260,6 +267,7 @@ static int dispatch_mask(bool backward, const SampleArgs& a, hipStream_t stream)
                         : launch_dense_forward<T, D, C, MK>(a, stream);
     switch (mask) {
         PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
+        PIGS_CASE(32)
         default: break;
     }
 #undef PIGS_CASE

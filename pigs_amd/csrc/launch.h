@@ -14,6 +14,8 @@ struct SampleArgs {
     void* out[4];          // forward outputs (orders 0..3)
     const void* gout[4];   // backward: incoming gradients
     void *g_means, *g_conics, *g_values;
+    double resid[4];       // orders_mask == 32 (linear residual): a0, a1x, a1y, aL
+    const void* target;    //   and its target [M][c] (or null)
 };
 
 int dense_dispatch(bool backward, const SampleArgs& a, hipStream_t stream);
@@ -51,10 +53,11 @@ int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags
                float q_max, float q_max_backward, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream);
 int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
-                 float q_max, int mask, void* const* out, hipStream_t stream);
+                 float q_max, int mask, void* const* out, hipStream_t stream, const double* resid = nullptr,
+                 const void* target = nullptr);
 int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
                   float q_max, int mask, const void* const* gout, void* g_means, void* g_conics, void* g_values,
-                  hipStream_t stream);
+                  hipStream_t stream, const double* resid = nullptr);
 int plan_layout_info(int64_t N, int64_t M, int c, int64_t* info);
 // the Gaussian grid alone (aggregate.hip): plan.hip
 size_t aggregate_grid_bytes(int64_t N);
@@ -65,11 +68,13 @@ size_t plan_error_offset();
 
 // Order masks: bit k < 4 = derivative order k (pointer slot k); bit 4 (16) = the TRACE of the order-2
 // output (the Laplacian), which takes pointer slot 2 in place of the full Hessian, [M][c].
+// 32 = the linear residual (pair_math.h ORDR), alone, in slot 0 -- reachable through pigs_residual_* only.
 inline bool mask_valid(int m) { return m > 0 && m < 32 && !((m & 4) && (m & 16)); }
-inline bool mask_uses_slot(int m, int k) { return (m >> k & 1) || (k == 2 && (m & 16)); }
+inline bool mask_uses_slot(int m, int k) { return m == 32 ? k == 0 : (m >> k & 1) || (k == 2 && (m & 16)); }
 // Smallest compiled mask covering the request (compiled: single orders, 0..2, 0..3, the trace alone
 // and orders 0, 1 + trace); 0 = no compiled kernel (trace together with order 3).
 inline int covering_mask_of(int mask) {
+    if (mask == 32) return 32;
     if (mask & 16) return mask == 16 ? 16 : (mask & ~19) == 0 ? 19 : 0;
     if (mask == 1 || mask == 2 || mask == 4 || mask == 8) return mask;
     if ((mask & ~7) == 0) return 7;

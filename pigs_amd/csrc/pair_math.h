@@ -19,6 +19,19 @@ constexpr int ORD0 = 1, ORD1 = 2, ORD2 = 4, ORD3 = 8;
 // trace of the Hessian (the Laplacian the PDE residuals consume, model_pn.py:614-617) instead of
 // the full Hessian: one value per channel in the order-2 slot; never together with ORD2
 constexpr int ORD2T = 16;
+// A LINEAR RESIDUAL of the sampled field as the only output (mask == ORDR, alone):
+//   r[m][c] = a0 u + a1 . grad u + aL (u_xx + u_yy) - target[m][c]
+// -- the diffusion / wave residuals of the reference's losses (model_pn.py:612-617, 834-849;
+// test_no_mlp.py:127-144: u_t - D lap u with u_t = (u - u_prev) / dt) in one launch and 4 B per point and
+// channel instead of u, grad u and the Hessian (28 B).  Its backward is the backward of orders 0, 1 and
+// the trace with the incoming gradients a0 gr, a1 gr, aL gr formed on the fly.
+constexpr int ORDR = 32;
+constexpr int ORDR_AS = ORD0 | ORD1 | ORD2T;      // the order mask whose backward arithmetic a residual uses
+
+template <typename T> struct Resid {
+    T a0, a1[2], aL;
+    const T* target;      // [M][c] or null
+};
 
 template <int D> struct Sym {
     static constexpr int NF = D * (D + 1) / 2;            // distinct 2nd-order components
@@ -47,7 +60,7 @@ template <int D, int C, int MASK> struct FwdLayout {
     static constexpr int O1 = O0 + ((MASK & ORD0) ? C : 0);
     static constexpr int O2 = O1 + ((MASK & ORD1) ? D * C : 0);
     static constexpr int O3 = O2 + ((MASK & ORD2) ? Sym<D>::NF * C : (MASK & ORD2T) ? C : 0);
-    static constexpr int N = O3 + ((MASK & ORD3) ? Sym<D>::N3 * C : 0);
+    static constexpr int N = O3 + ((MASK & ORD3) ? Sym<D>::N3 * C : 0) + ((MASK & ORDR) ? C : 0);
 };
 
 // Pair geometry: x, p, g (and nothing else) for one (point, Gaussian).
@@ -71,10 +84,25 @@ template <typename T, int D> struct Pair {
 // acc += contributions of one Gaussian to the outputs selected by MASK at one sample point.
 // The order-1 accumulator holds +sum(p w); the sign is applied on store.
 template <typename T, int D, int C, int MASK>
-__device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, const T* con, const T* v) {
+__device__ __forceinline__ void fwd_accumulate(T* acc, const T* s, const T* mu, const T* con, const T* v,
+                                               const Resid<T>* rz = nullptr) {
     using L = FwdLayout<D, C, MASK>;
     Pair<T, D> pr;
     pr.eval(s, mu, con);
+    if constexpr (MASK == ORDR) {
+        // one polynomial factor per pair, one accumulator per channel: a0 - a1 . p + aL (|p|^2 - tr C)
+        T F;
+        if constexpr (D == 1) {
+            F = fma_<T>(rz->aL, fma_<T>(pr.p[0], pr.p[0], -con[0]), fma_<T>(-rz->a1[0], pr.p[0], rz->a0));
+        } else {
+            const T ttr = fma_<T>(pr.p[0], pr.p[0], fma_<T>(pr.p[1], pr.p[1], -(con[0] + con[2])));
+            F = fma_<T>(rz->aL, ttr, fma_<T>(-rz->a1[0], pr.p[0], fma_<T>(-rz->a1[1], pr.p[1], rz->a0)));
+        }
+        const T Fg = F * pr.g;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) acc[ch] = fma_<T>(v[ch], Fg, acc[ch]);
+        return;
+    }
     if constexpr ((MASK & ORD3) != 0) {
         // a pair whose g has underflowed to zero contributes nothing, but its cubic factor can
         // overflow (|p| > 7e12: conics of 1e12 from |rho| -> 1) and 0 * inf would poison the sum
@@ -151,8 +179,14 @@ __device__ __forceinline__ void store_out(T* p, T v) {
 }
 template <typename T, int D, int C, int MASK, bool STREAM = false>
 __device__ __forceinline__ void fwd_store(const T* acc, int64_t m, T* __restrict__ o0, T* __restrict__ o1,
-                                          T* __restrict__ o2, T* __restrict__ o3) {
+                                          T* __restrict__ o2, T* __restrict__ o3, const Resid<T>* rz = nullptr) {
     using L = FwdLayout<D, C, MASK>;
+    if constexpr (MASK == ORDR) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)
+            store_out<STREAM>(&o0[m * C + ch], rz->target ? acc[ch] - rz->target[m * C + ch] : acc[ch]);
+        return;
+    }
     if constexpr ((MASK & ORD0) != 0) {
         if (o0) {
 #pragma unroll
@@ -304,6 +338,19 @@ template <typename T, int D, int C, int MASK> struct Gsym {
                         for (int k = 0; k < D; ++k)
                             g3[i + j + k][ch] += G3 ? G3[(((m * D + i) * D + j) * D + k) * C + ch] : T(0);
             }
+        }
+    }
+    // the incoming gradient gr [M][c] of a residual output (MASK = ORDR_AS): g0 = a0 gr, g1 = a1 gr, trace = aL gr
+    __device__ __forceinline__ void load_residual(int64_t m, const T* __restrict__ GR, const Resid<T>& rz) {
+        static_assert(MASK == ORDR_AS, "a residual's backward runs on orders 0, 1 and the trace");
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const T gr = GR[m * C + ch];
+            g0[ch] = rz.a0 * gr;
+#pragma unroll
+            for (int i = 0; i < D; ++i) g1[i][ch] = rz.a1[i] * gr;
+#pragma unroll
+            for (int k = 0; k < Sym<D>::NF; ++k) g2[k][ch] = (k == 0 || k == Sym<D>::NF - 1) ? rz.aL * gr : T(0);
         }
     }
 };

@@ -993,7 +993,8 @@ __device__ __forceinline__ Rec rec_of(const LdsRec<C>& x) {
 // reads of the next pair are in flight (the last issue reads the two rows behind the queue: inside
 // the LDS block, never used).
 template <int C, int MASK>
-__device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const FwdLds& lds, int rows, int lane) {
+__device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const FwdLds& lds, int rows, int lane,
+                                              const Resid<float>& rz) {
     static_assert(PIGS_FWD_UNROLL == 2, "two rows per register set");
     uint32_t q = lds_addr(lds.rec) + (uint32_t)(lane >> 4) * FwdLds::GSTRIDE;
     LdsRec<C> ra[2], rb[2];
@@ -1001,7 +1002,7 @@ __device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const Rec x = rec_of<C>(r[u]);
-            fwd_accumulate<float, 2, C, MASK>(acc, s, x.mu, x.con, x.v);
+            fwd_accumulate<float, 2, C, MASK>(acc, s, x.mu, x.con, x.v, &rz);
         }
     };
     lds_rec_issue<0>(ra[0], q);
@@ -1027,12 +1028,12 @@ __device__ __forceinline__ void evaluate_rows(float* acc, const float* s, const 
 template <int C, int MASK>
 constexpr int fwd_waves() {
     constexpr int n = FwdLayout<2, C, MASK>::N;
-    return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1)) ? PIGS_FWD_WAVES : 6;
+    return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1 || MASK == ORDR)) ? PIGS_FWD_WAVES : 6;
 }
 template <int C, int MASK>
 __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kernel(
     PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
-    float* __restrict__ o3) {
+    float* __restrict__ o3, Resid<float> rz) {
     using L = FwdLayout<2, C, MASK>;
     constexpr int U = PIGS_FWD_UNROLL;
     __shared__ FwdLds lds_all[4];
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         // waves outside the row loop (issuing loads, filling queues, storing) go first: their memory
         // requests are what the others' arithmetic hides (27.5 -> 27.3 us; the other way round 28.1)
         __builtin_amdgcn_s_setprio(0);
-        evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
+        evaluate_rows<C, MASK>(acc, s, lds, rows, lane, rz);
         __builtin_amdgcn_s_setprio(3);
 #else
         acc[0] += (float)rows + ((const float*)lds.rec)[lane];
@@ -1126,7 +1127,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
             wave_lds_fence();
             if (rows > 0) {
                 __builtin_amdgcn_s_setprio(0);
-                evaluate_rows<C, MASK>(acc, s, lds, rows, lane);
+                evaluate_rows<C, MASK>(acc, s, lds, rows, lane, rz);
                 __builtin_amdgcn_s_setprio(3);
             }
             qn = 0;
@@ -1162,10 +1163,10 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
     const bool stream = __builtin_popcountll(__ballot(valid && dist == 1u)) >= 48;
     if (valid) {
         if (stream) {
-            fwd_store<float, 2, C, MASK, true>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+            fwd_store<float, 2, C, MASK, true>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
             asm volatile("" ::: "memory");       // keeps the two branches' stores apart: merged into a common tail they lose the hint
         } else {
-            fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3);
+            fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
         }
     }
 }
@@ -1280,7 +1281,7 @@ __device__ __forceinline__ void quad_sums(float* z) {
 
 // rows: a multiple of 4 (split_step<4> pads the lists with the all-zero record; the sums of such rows
 // land behind the lists' ends in the table and are never read)
-template <int C, int MASK>
+template <int C, int MASK>      // MASK: the mask of the arithmetic (a residual's: ORDR_AS)
 __device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 2, C, MASK>& G,
                                               TileLdsBwd<BwdLayout<2, C>::N>& lds, int rows, int lane) {
     using BL = BwdLayout<2, C>;
@@ -1348,12 +1349,13 @@ constexpr int bwd_waves() {
     // c = 2: the sums table has 8 floats per row (NV = 7), 47.7 KB of LDS per workgroup -> 3 workgroups per
     // CU whatever the registers allow, so every c = 2 variant asks for 3 waves (168 VGPRs: no spills in
     // the widest gradient sets either); c = 1 with order 3 the same for its registers
-    return (C == 2 || MASK == 15) ? 3 : (MASK == 7 || MASK == 19 || MASK == 1 || MASK == 2) ? PIGS_BWD_WAVES : 4;
+    return (C == 2 || MASK == 15) ? 3 : (MASK == 7 || MASK == 19 || MASK == ORDR || MASK == 1 || MASK == 2) ? PIGS_BWD_WAVES : 4;
 }
 template <int C, int MASK>
 __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
     PlanView pv, SamplesView sv, const float* __restrict__ G0p, const float* __restrict__ G1p,
-    const float* __restrict__ G2p, const float* __restrict__ G3p) {
+    const float* __restrict__ G2p, const float* __restrict__ G3p, Resid<float> rz) {
+    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;      // a residual's backward = orders 0, 1, trace
     using BL = BwdLayout<2, C>;
     constexpr int NV = BL::N;
     constexpr int S = TileLdsBwd<NV>::S;
@@ -1367,8 +1369,9 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     const bool valid = m < sv.M;
     const SPoint sp = sv.spts[valid ? m : sv.M - 1];
     const float s[2] = {sp.x, sp.y};
-    Gsym<float, 2, C, MASK> G;
-    G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
+    Gsym<float, 2, C, EM> G;
+    if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
+    else G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
     if (!valid) {               // lanes behind the last point contribute nothing
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     // the tile's points are scattered, which is when lists overflow).  Built only when the walk meets
     // such a tile, and outside `step`.
     // gradients that arrive at second / third derivatives (or the trace) use the plan's wide cut-off (plan.h)
-    constexpr bool WIDE = (MASK & (ORD2 | ORD3 | 16)) != 0;
+    constexpr bool WIDE = (EM & (ORD2 | ORD3 | ORD2T)) != 0;
     auto ranges_mask = [&]() {
         const float INF = __builtin_huge_valf();
         const float q_cut = WIDE ? pv.params->q_b : pv.params->q_f;
@@ -1415,7 +1418,7 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
         int rank[4];
         const int rows = split_step<4>(lds.t, gm, lane, rank);
         wave_lds_fence();
-        backward_rows<C, MASK>(s, G, lds, rows, lane);
+        backward_rows<C, EM>(s, G, lds, rows, lane);
         wave_lds_fence();
         if (have && gm != 0u) {               // this lane's entry: its rows of the table, one atomic per value
             float sum[S];
@@ -1650,16 +1653,17 @@ int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags
 }
 
 template <int C>
-static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, float* const* out, hipStream_t stream) {
+static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, float* const* out, hipStream_t stream,
+                          const Resid<float>& rz) {
     const dim3 grid((sv.ntiles + 3) / 4), block(256);
     clear_hip_error();
 #define PIGS_CASE(MK)                                                                                          \
     case MK:                                                                                                   \
         hipLaunchKernelGGL((tile_forward_kernel<C, MK>), grid, block, 0, stream, pv, sv, out[0], out[1], out[2], \
-                           out[3]);                                                                            \
+                           out[3], rz);                                                                        \
         break;
     switch (mask) {
-        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19) PIGS_CASE(32)
         default: return PIGS_ERR_UNSUPPORTED;
     }
 #undef PIGS_CASE
@@ -1668,15 +1672,15 @@ static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, f
 
 template <int C>
 static int plan_backward_c(const PlanView& pv, const SamplesView& sv, int mask, const float* const* g, float* gm,
-                           float* gc, float* gv, hipStream_t stream) {
+                           float* gc, float* gv, hipStream_t stream, const Resid<float>& rz) {
     const dim3 grid((sv.ntiles + 3) / 4), block(256);
     clear_hip_error();
 #define PIGS_CASE(MK)                                                                                             \
     case MK:                                                                                                      \
-        hipLaunchKernelGGL((tile_backward_kernel<C, MK>), grid, block, 0, stream, pv, sv, g[0], g[1], g[2], g[3]); \
+        hipLaunchKernelGGL((tile_backward_kernel<C, MK>), grid, block, 0, stream, pv, sv, g[0], g[1], g[2], g[3], rz); \
         break;
     switch (mask) {
-        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19)
+        PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19) PIGS_CASE(32)
         default: return PIGS_ERR_UNSUPPORTED;
     }
 #undef PIGS_CASE
@@ -1684,8 +1688,15 @@ static int plan_backward_c(const PlanView& pv, const SamplesView& sv, int mask, 
     return launch_status();
 }
 
+static Resid<float> resid_of(const double* r, const void* target) {
+    Resid<float> rz{};
+    if (r) { rz.a0 = (float)r[0]; rz.a1[0] = (float)r[1]; rz.a1[1] = (float)r[2]; rz.aL = (float)r[3]; }
+    rz.target = (const float*)target;
+    return rz;
+}
+
 int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
-                 float q_max, int mask, void* const* out, hipStream_t stream) {
+                 float q_max, int mask, void* const* out, hipStream_t stream, const double* resid, const void* target) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
     const PlanLayout p = make_plan_layout(N, M, c);
     const SamplesLayout s = make_samples_layout(M);
@@ -1696,15 +1707,15 @@ int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, i
     for (int k = 0; k < 4; ++k) o[k] = mask_uses_slot(mask, k) ? (float*)out[k] : nullptr;
     const int cm = covering_mask_of(mask);
     switch (c) {
-        case 1: return plan_forward_c<1>(pv, sv, cm, o, stream);
-        case 2: return plan_forward_c<2>(pv, sv, cm, o, stream);
+        case 1: return plan_forward_c<1>(pv, sv, cm, o, stream, resid_of(resid, target));
+        case 2: return plan_forward_c<2>(pv, sv, cm, o, stream, resid_of(resid, target));
     }
     return PIGS_ERR_UNSUPPORTED;
 }
 
 int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
                   float q_max, int mask, const void* const* gout, void* g_means, void* g_conics, void* g_values,
-                  hipStream_t stream) {
+                  hipStream_t stream, const double* resid) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
     const PlanLayout p = make_plan_layout(N, M, c);
     const SamplesLayout s = make_samples_layout(M);
@@ -1715,8 +1726,8 @@ int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, 
     for (int k = 0; k < 4; ++k) g[k] = mask_uses_slot(mask, k) ? (const float*)gout[k] : nullptr;
     const int cm = covering_mask_of(mask);
     switch (c) {
-        case 1: return plan_backward_c<1>(pv, sv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
-        case 2: return plan_backward_c<2>(pv, sv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream);
+        case 1: return plan_backward_c<1>(pv, sv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream, resid_of(resid, nullptr));
+        case 2: return plan_backward_c<2>(pv, sv, cm, g, (float*)g_means, (float*)g_conics, (float*)g_values, stream, resid_of(resid, nullptr));
     }
     return PIGS_ERR_UNSUPPORTED;
 }

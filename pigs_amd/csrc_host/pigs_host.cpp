@@ -325,6 +325,99 @@ Outs sample_apply(const at::Tensor& means, const at::Tensor& values, const at::T
 }
 
 // ---------------------------------------------------------------------------------------------
+// residual(): r = a0 u + a1 . grad u + aL lap u - target in one launch (pigs_residual_*); the node owns its
+// inputs and plan like SampleBackward.
+// ---------------------------------------------------------------------------------------------
+struct PlanPtrs {
+    void *pw, *sw;
+    size_t pb, sb;
+};
+PlanPtrs plan_ptrs(Plan* plan, hipStream_t stream) {
+    if (!plan) return {nullptr, nullptr, 0, 0};
+    plan->note_stream(stream);
+    return {plan->workspace.data_ptr(), plan->samples->workspace.data_ptr(), (size_t)plan->workspace.numel(),
+            (size_t)plan->samples->workspace.numel()};
+}
+
+struct ResidualBackward : public torch::autograd::Node {
+    at::Tensor means, values, conics, samples;
+    uint32_t versions[4] = {0, 0, 0, 0};
+    double coeffs[4] = {0, 0, 0, 0};
+    bool debug = false, has_target = false;
+    at::ScalarType target_dtype = at::kFloat;
+    std::shared_ptr<Plan> plan;
+
+    std::string name() const override { return "PigsResidualBackward"; }
+    void release_variables() override {}
+
+    torch::autograd::variable_list apply(torch::autograd::variable_list&& grads) override {
+        if (means._version() != versions[0] || values._version() != versions[1] || conics._version() != versions[2] ||
+            samples._version() != versions[3])
+            throw std::runtime_error(
+                "one of the tensors handed to GaussianSampler.preprocess() has been modified in place before the "
+                "backward of a residual() output that was computed from it");
+        torch::autograd::variable_list res(has_target ? 4 : 3);
+        if (grads.empty() || !grads[0].defined()) return res;
+        at::AutoGradMode no_grad(false);
+        if (grads[0].requires_grad()) throw std::runtime_error("GaussianSampler.residual() is differentiable once");
+        const at::Tensor gout = grads[0].contiguous();
+        const int64_t N = means.size(0), d = means.size(1), c = values.size(1), M = samples.size(0);
+        at::Tensor g_means = at::empty_like(means), g_values = at::empty_like(values), g_conics = at::empty_like(conics);
+        if (N > 0 && M > 0) {
+            c10::DeviceGuard guard(means.device());
+            const hipStream_t stream = current_stream(means);
+            const PlanPtrs pp = plan_ptrs(plan.get(), stream);
+            check(pigs_residual_backward(dtype_code(means), (int)d, (int)c, N, M, ptr(means), ptr(conics), ptr(values), ptr(samples),
+                                         coeffs, ptr(gout), ptr(g_means), ptr(g_conics), ptr(g_values), pp.pw, pp.pb, pp.sw, pp.sb,
+                                         stream),
+                  "pigs_residual_backward");
+        } else {
+            g_means.zero_(); g_values.zero_(); g_conics.zero_();
+        }
+        if (debug) device_sync(means);
+        res[0] = g_means; res[1] = g_values; res[2] = g_conics;
+        if (has_target && task_should_compute_output(3)) res[3] = gout.neg().to(target_dtype);
+        return res;
+    }
+};
+
+at::Tensor residual_apply(const at::Tensor& means, const at::Tensor& values, const at::Tensor& conics, const at::Tensor& samples,
+                          const std::array<double, 4>& coeffs, const c10::optional<at::Tensor>& target, bool debug,
+                          const std::shared_ptr<Plan>& plan) {
+    const int64_t N = means.size(0), d = means.size(1), c = values.size(1), M = samples.size(0);
+    at::Tensor tgt;
+    if (target.has_value()) {
+        at::AutoGradMode no_grad(false);
+        tgt = target->detach().to(means.scalar_type()).contiguous();
+    }
+    at::Tensor out = at::empty({M, c}, means.options());
+    if (M > 0) {
+        c10::DeviceGuard guard(means.device());
+        const hipStream_t stream = current_stream(means);
+        const PlanPtrs pp = plan_ptrs(plan.get(), stream);
+        check(pigs_residual_forward(dtype_code(means), (int)d, (int)c, N, M, ptr(means), ptr(conics), ptr(values), ptr(samples),
+                                    coeffs.data(), ptr(tgt), ptr(out), pp.pw, pp.pb, pp.sw, pp.sb, stream),
+              "pigs_residual_forward");
+    }
+    if (debug) device_sync(means);
+    const bool tgrad = target.has_value() && target->requires_grad();
+    if (at::GradMode::is_enabled() && (means.requires_grad() || values.requires_grad() || conics.requires_grad() || tgrad)) {
+        std::shared_ptr<ResidualBackward> node(new ResidualBackward(), torch::autograd::deleteNode);
+        if (target.has_value()) node->set_next_edges(torch::autograd::collect_next_edges(means, values, conics, *target));
+        else node->set_next_edges(torch::autograd::collect_next_edges(means, values, conics));
+        node->means = means; node->values = values; node->conics = conics; node->samples = samples;
+        node->versions[0] = means._version(); node->versions[1] = values._version();
+        node->versions[2] = conics._version(); node->versions[3] = samples._version();
+        for (int k = 0; k < 4; ++k) node->coeffs[k] = coeffs[k];
+        node->debug = debug; node->plan = plan;
+        node->has_target = target.has_value();
+        if (target.has_value()) node->target_dtype = target->scalar_type();
+        torch::autograd::create_gradient_edge(out, node);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // preprocess_aggregate / aggregate_neighbors (model_pn.py:257-264; parity unpinned: this repository's own
 // definition, pigs_amd/csrc/aggregate.hip).  Same structure as pigs_amd/aggregate.py.
 // ---------------------------------------------------------------------------------------------
@@ -646,6 +739,11 @@ struct Core {
         return res;
     }
 
+    at::Tensor residual(const std::array<double, 4>& coeffs, const c10::optional<at::Tensor>& target) {
+        require_inputs();
+        return residual_apply(means, values, conics, samples, coeffs, target, debug, plan);
+    }
+
     void preprocess_aggregate(int64_t cap) {
         require_inputs();
         if (means.size(1) != 2) raise_py(PyExc_NotImplementedError, "aggregate_neighbors is implemented for d = 2");
@@ -743,6 +841,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("get", &Core::get)
         .def("sample", &Core::sample)
         .def("inputs", &Core::inputs)
+        .def("residual", &Core::residual, py::arg("coeffs"), py::arg("target") = c10::optional<at::Tensor>())
         .def("preprocess_aggregate", &Core::preprocess_aggregate, py::arg("cap") = -1)
         .def("aggregate_neighbors", &Core::aggregate_neighbors)
         .def_readonly("neighbors", &Core::neighbors)

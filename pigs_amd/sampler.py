@@ -290,6 +290,70 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
     return g_means, g_values, g_conics
 
 
+def _residual_call(backward, means, values, conics, samples, coeffs, plan, target=None, gout=None):
+    """pigs_residual_forward / _backward on contiguous device tensors (through the plan when given)."""
+    lib = _lib.load()
+    N, d = means.shape
+    c = values.shape[1]
+    M = samples.shape[0]
+    cf = (ctypes.c_double * 4)(*coeffs)
+    pw = (_ptr(plan.workspace), plan.workspace.numel(), _ptr(plan.samples.workspace), plan.samples.workspace.numel()) \
+        if plan is not None else (ctypes.c_void_p(0), 0, ctypes.c_void_p(0), 0)
+    with _on_device(means.device):
+        stream = _stream(means.device)
+        if plan is not None and hasattr(plan, "note_stream"):
+            plan.note_stream(stream.value)
+        if not backward:
+            out = torch.empty((M, c), dtype=means.dtype, device=means.device)
+            if M > 0:
+                rc = lib.pigs_residual_forward(_DTYPES[means.dtype], d, c, N, M, _ptr(means), _ptr(conics), _ptr(values),
+                                               _ptr(samples), cf, _ptr(target), _ptr(out), *pw, stream)
+                _lib.check(rc, "pigs_residual_forward")
+            return out
+        g_means, g_values, g_conics = torch.empty_like(means), torch.empty_like(values), torch.empty_like(conics)
+        if N > 0:
+            if M > 0:
+                rc = lib.pigs_residual_backward(_DTYPES[means.dtype], d, c, N, M, _ptr(means), _ptr(conics), _ptr(values),
+                                                _ptr(samples), cf, _ptr(gout), _ptr(g_means), _ptr(g_conics), _ptr(g_values),
+                                                *pw, stream)
+                _lib.check(rc, "pigs_residual_backward")
+            else:
+                for g in (g_means, g_values, g_conics):
+                    g.zero_()
+        return g_means, g_values, g_conics
+
+
+class _ResidualFunction(torch.autograd.Function):
+    """r = a0 u + a1 . grad u + aL lap u - target in one launch; its backward is one launch too.  The node
+    owns its inputs and plan like :class:`_SampleFunction`."""
+
+    @staticmethod
+    def forward(ctx, means, values, conics, samples, target, coeffs, debug, plan):
+        tgt = None if target is None else target.detach().to(means.dtype).contiguous()
+        out = _residual_call(False, means, values, conics, samples, coeffs, plan, target=tgt)
+        if debug:
+            torch.cuda.synchronize(means.device)
+        ctx.inputs = (means, values, conics, samples)
+        ctx.versions = (means._version, values._version, conics._version, samples._version)
+        ctx.coeffs, ctx.debug, ctx.plan = coeffs, debug, plan
+        ctx.target_dtype = None if target is None else target.dtype
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        means, values, conics, samples = ctx.inputs
+        if (means._version, values._version, conics._version, samples._version) != ctx.versions:
+            raise RuntimeError("one of the tensors handed to GaussianSampler.preprocess() has been modified in place "
+                               "before the backward of a residual() output that was computed from it")
+        gout = gout.contiguous()
+        g_means, g_values, g_conics = _residual_call(True, means, values, conics, samples, ctx.coeffs, ctx.plan, gout=gout)
+        if ctx.debug:
+            torch.cuda.synchronize(means.device)
+        g_target = None if ctx.target_dtype is None or not ctx.needs_input_grad[4] else (-gout).to(ctx.target_dtype)
+        return g_means, g_values, g_conics, None, g_target, None, None, None
+
+
 class _SampleFunction(torch.autograd.Function):
     """One fused launch producing the outputs of every order in ``mask``; its backward is one
     fused launch over the outputs that received a gradient.
@@ -630,6 +694,31 @@ class GaussianSampler:
         if TRACE in orders and TRACE not in self._cache:
             self._cache[TRACE] = self._cache[2].diagonal(dim1=1, dim2=2).sum(-1)
         return tuple(self._cache[o] for o in orders)
+
+    def residual(self, a0=0.0, a1=None, lap=0.0, target=None):
+        """Extension of the reference API: the linear residual
+        ``r = a0 u + a1 . grad u + lap (u_xx + u_yy) - target`` as [M, c] in ONE launch (4 bytes per point and
+        channel instead of the 28 of u, grad u and the Hessian), differentiable wrt means, values, conics (one
+        launch) and ``target``.  ``a0``, ``lap``: floats; ``a1``: d floats (default zero); ``target``: [M, c]
+        (or [M] for c = 1) or None.  The reference's diffusion loss (model_pn.py:612-617, 834-849;
+        test_no_mlp.py:127-144: ``(u - u_prev) / dt - D lap u``) is
+        ``sampler.residual(a0=1 / dt, lap=-D, target=u_prev / dt).pow(2).mean()``.  Binned plans evaluate the
+        backward with the wide cut-off ``q_max_backward``."""
+        means, values, conics, samples = self._require_inputs()
+        d, c, M = means.shape[1], values.shape[1], samples.shape[0]
+        a1 = (0.0,) * d if a1 is None else tuple(float(x) for x in (a1 if hasattr(a1, "__len__") else (a1,)))
+        if len(a1) != d:
+            raise ValueError(f"a1 must hold d = {d} coefficients")
+        coeffs = (float(a0), a1[0], a1[1] if d == 2 else 0.0, float(lap))
+        if target is not None:
+            if not isinstance(target, torch.Tensor) or not target.is_cuda:
+                raise RuntimeError("target must be a tensor on the GPU (no CPU fallback)")
+            if target.numel() != M * c:
+                raise ValueError(f"target must hold M*c = {M * c} elements, got {tuple(target.shape)}")
+            target = target.reshape(M, c)
+        if self._core is not None:
+            return self._core.residual(coeffs, target)
+        return _ResidualFunction.apply(means, values, conics, samples, target, coeffs, self.debug, self._plan)
 
     def sample_gaussians(self):
         """u [M, c]"""
