@@ -421,11 +421,14 @@ def main():
                     "frac_of_pair_peak": pr["pairs"] / (k_ms * 1e-3) / VALU_PAIR_PEAK,
                     "issue_frac": instr / (k_ms * 1e-3) / VALU_ISSUE_PEAK,
                     "row_loop_floor_ms": pr["wave_rows"] * ROW_NS_UBENCH * 1e-6 / 1024,
+                    "ceiling_frac": algo_bytes / (instr / VALU_ISSUE_PEAK) / HBM_PEAK,
                     "what": "pairs = (point, Gaussian) evaluations of one launch, from the tile headers; issue_frac = "
                             f"wave_rows x {ROW_VALU_INSTR} VALU instructions (ISA count of the row loop) / kernel time / "
                             "(1024 SIMDs x 1 instruction per 2 cycles x 2.4 GHz); row_loop_floor_ms = wave_rows x the "
                             f"{ROW_NS_UBENCH} ns a row costs in the bare row loop at 8 waves/SIMD (tools/ubench/rowloop.hip) "
-                            "/ 1024 SIMDs: what the launch would take if it were only that loop"}
+                            "/ 1024 SIMDs: what the launch would take if it were only that loop; ceiling_frac = the HBM-roofline "
+                            "fraction this float32-VALU formulation could reach at this density if the launch were nothing "
+                            "but the row loop's instructions at the 2-cycle issue peak (read it beside `frac`)"}
         return r
 
     roofline = roofline_of(sampler, a.kappa)
@@ -561,6 +564,42 @@ def main():
             r13 = roofline_of(s13, 1.3)
             kappa13 = {"value": M * world / (d13 / n13), "ms_per_step": d13 / n13 * 1e3, "steps": n13,
                        "kernel_ms": r13["kernel_ms"], "frac": r13["frac"], "valu": r13.get("valu")}
+            if not a.no_bwd:
+                m13, v13, c13, sm13 = s13._inputs
+                with torch.no_grad():
+                    go13 = [torch.randn((M,) + (2,) * k + (1,), device=dev) for k in range(3)] + [None, None]
+                    kappa13["bwd_kernel_ms"] = kernel_ms(lambda: S.backward_raw(m13, v13, c13, sm13, go13, 7, s13._plan), 5)
+                kappa13["bwd_frac"] = (48 * N + 36 * M) / (kappa13["bwd_kernel_ms"] * 1e-3) / HBM_PEAK
+
+    c2 = None
+    if not a.no_extras and dist is None and a.workload == "c3":
+        # BASELINE configs[1]: 8k Gaussians x 256^2 grid, fwd + deriv + bwd on one GPU (same kappa)
+        try:
+            gs2 = synthetic.lattice_gaussians(128, 64, a.kappa, seed=0)
+            t2 = {k: v.float().to(dev) for k, v in gs2.items()}
+            p2 = synthetic.grid_samples(256, 256).float().to(dev)
+            s2, step2 = forward_only(t2, p2, False)
+            with torch.no_grad():
+                settle(step2)
+                d2 = timed_steps(step2, 10, 100) / 100
+            req2 = {k: t2[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
+            sw2 = GaussianSampler(False, fuse="all", backend=a.backend)
+            g2 = []
+
+            def fb2():
+                sw2.preprocess(req2["means"], req2["values"], t2["covariances"], req2["conics"], p2)
+                outs = sw2.sample((0, 1, 2))
+                if not g2:
+                    g2.extend(torch.randn_like(o) for o in outs)
+                return torch.autograd.grad(outs, list(req2.values()), grad_outputs=g2)
+            settle(fb2)
+            dfb = timed_steps(fb2, 10, 100) / 100
+            c2 = {"workload": "c2: 8192 Gaussians x 256x256 grid, d=2, c=1, orders 0-2", "path": "binned" if s2._plan is not None else "dense",
+                  "value": p2.shape[0] / d2, "ms_per_step": d2 * 1e3, "fwd_bwd_sampler_only_ms_per_step": dfb * 1e3,
+                  "what": "value: cold preprocess + fused forward (orders 0..2); fwd_bwd: preprocess (samples half reused) + "
+                          "fused forward + fused backward, incoming gradients supplied, eager"}
+        except Exception as e:
+            c2 = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     line = {
         "metric": "sample-points/sec (fwd + 1st + 2nd derivatives, fused)", "value": value,
@@ -575,7 +614,7 @@ def main():
         "host_issue_ms_per_step": host_cold * 1e3,
         "preheat_ms": preheat_ms, "value_warm_plan": warm["value"], "warm_plan": warm,
         "roofline": roofline, "roofline_bwd": roofline_bwd, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
-        "kappa_1_3": kappa13, "small": small, "host": sampler.host,
+        "kappa_1_3": kappa13, "small": small, "c2": c2, "host": sampler.host,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(gs, pts)

@@ -110,8 +110,8 @@ int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, c
  * backward of gradients that arrive at order 2, order 3 or the trace (a value <= q_max, 0 included,
  * means one cut-off).  Why: the conic gradient of a second-derivative term carries a q^2 prefactor and
  * its sum over the points nearly cancels, so with thousands of points per Gaussian and one-signed
- * incoming gradients the tail beyond q = 36 was 2.4e-5 of the largest entry; at 44 it is 1e-6
- * (DESIGN.md "Cut-off").  The same (N, M, c) and the same samples workspace must be passed to every
+ * incoming gradients the tail beyond q = 36 was 2.5e-5 of the largest entry; at 40 (the Python host's
+ * default) it is 3.5e-6, the dense kernel's own float32 error level (DESIGN.md "Cut-off").  The same (N, M, c) and the same samples workspace must be passed to every
  * call on a plan workspace; the plan remembers its cut-offs (the q_max argument of pigs_plan_forward /
  * pigs_plan_backward is kept for ABI shape and ignored since ABI 6).  pigs_plan_backward uses scratch
  * inside the plan workspace: calls sharing one must be stream ordered.

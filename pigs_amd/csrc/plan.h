@@ -64,9 +64,10 @@ constexpr int PLAN_BBOX_BLOCKS = 256;
 // (narrow mask, also what the group lists hold); the backward of gradients that arrive at second (or
 // third) derivatives uses the q <= q_b ellipse (wide mask; q_b >= q_f): the conic gradient of such a
 // term carries a q^2 prefactor AND its per-Gaussian sum nearly cancels (the plane integral of a
-// derivative of a Gaussian vanishes), so the tail dropped at q = 36 was 2.4e-5 of the largest entry with
-// thousands of points per Gaussian and one-signed incoming gradients (tests/test_fuzz_gpu.py,
-// tools/fuzz_diag.py); at q_b = 44 it is 1e-6.
+// derivative of a Gaussian vanishes), so the tail dropped at q = 36 was up to 2.5e-5 of the largest entry
+// with thousands of points per Gaussian and one-signed incoming gradients (tests/test_fuzz_gpu.py,
+// tools/fuzz_diag.py); at q_b = 40 (the host's default) it is 3.5e-6, the level of the dense kernel's own
+// float32 accumulation error on the same cases (3.3e-6); 44 buys nothing more (3.4e-6).
 constexpr int LIST_IDX_BITS = 24;
 constexpr uint32_t LIST_IDX_MASK = (1u << LIST_IDX_BITS) - 1u;
 constexpr int LIST_WIDE_SHIFT = 24, LIST_NARROW_SHIFT = 28;

@@ -435,9 +435,10 @@ class GaussianSampler:
     plan built on first use: dropped terms carry a q^1.5 prefactor there, q^2.5 in its conic
     gradient -- tools/fuzz_stats.py: 2 of 300 adversarial cases left the 1e-5 bar at 36, none at
     40; the backward of gradients that arrive at second derivatives (or the trace) uses
-    ``q_max_backward``, default q_max + 8, through wider group masks kept in the SAME plan: the conic
-    gradient of such a term carries q^2 and its sum nearly cancels -- tools/fuzz_diag.py: 2.4e-5 of the
-    largest entry at 36, 1e-6 at 44); ``"auto"`` picks
+    ``q_max_backward``, default q_max + 4, through wider group masks kept in the SAME plan: the conic
+    gradient of such a term carries q^2 and its sum nearly cancels -- tools/fuzz_diag.py, worst of the four
+    worst fuzz cases: 2.5e-5 of the largest entry at 36, 3.5e-6 at 40 -- the dense kernel's own float32
+    error on those cases is 3.3e-6 -- 3.4e-6 at 44); ``"auto"`` picks
     binned for float32, d = 2, c <= 2 once N*M >= 2**26 pairs, where the plan pays for itself.
 
     ``reuse_samples`` (extension, keyword only; binned path): when ``preprocess`` is called again with a
@@ -505,7 +506,7 @@ class GaussianSampler:
         self.q_max_order3 = float(q_max_order3) if q_max_order3 is not None else self.q_max + 8.0
         if self.q_max_order3 < self.q_max:
             raise ValueError("q_max_order3 must not be below q_max")
-        self.q_max_backward = float(q_max_backward) if q_max_backward is not None else self.q_max + 8.0
+        self.q_max_backward = float(q_max_backward) if q_max_backward is not None else self.q_max + 4.0
         if self.q_max_backward < self.q_max:
             raise ValueError("q_max_backward must not be below q_max")
         self.reuse_samples = 4 if reuse_samples is True else max(0, int(reuse_samples))

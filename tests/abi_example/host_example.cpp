@@ -67,9 +67,9 @@ int main(int argc, char** argv) {
     void *sws, *ws;
     CHECK_HIP(hipMalloc(&sws, sb)); CHECK_HIP(hipMalloc(&ws, pb));
     const float q_max = 36.f;
-    CHECK_PIGS(pigs_plan_build(ws, pb, sws, sb, PIGS_BUILD_SAMPLES, N, M, c, q_max, q_max + 8.f, d_means, d_conics, d_values, d_samples, stream));
+    CHECK_PIGS(pigs_plan_build(ws, pb, sws, sb, PIGS_BUILD_SAMPLES, N, M, c, q_max, q_max + 4.f, d_means, d_conics, d_values, d_samples, stream));
     // the same Gaussians again on the existing samples workspace, into the same (now clean) plan workspace
-    CHECK_PIGS(pigs_plan_build(ws, pb, sws, sb, PIGS_BUILD_PLAN_WS_CLEAN, N, M, c, q_max, q_max + 8.f, d_means, d_conics, d_values, d_samples, stream));
+    CHECK_PIGS(pigs_plan_build(ws, pb, sws, sb, PIGS_BUILD_PLAN_WS_CLEAN, N, M, c, q_max, q_max + 4.f, d_means, d_conics, d_values, d_samples, stream));
     CHECK_PIGS(pigs_plan_forward(ws, pb, sws, sb, N, M, c, q_max, 0x7, b0, b1, b2, nullptr, stream));
     CHECK_PIGS(pigs_plan_backward(ws, pb, sws, sb, N, M, c, q_max, 0x7, d_g0, d_g1, d_g2, nullptr, gm, gc, gv, stream));
     // the samples half on its own (pigs_samples_build), then a plan on top of it: the same forward results
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     float* b0_2;
     CHECK_HIP(hipMalloc(&sws2, sb)); CHECK_HIP(hipMalloc(&ws2, pb)); CHECK_HIP(hipMalloc(&b0_2, M * c * 4));
     CHECK_PIGS(pigs_samples_build(sws2, sb, M, d_samples, stream));
-    CHECK_PIGS(pigs_plan_build(ws2, pb, sws2, sb, 0, N, M, c, q_max, q_max + 8.f, d_means, d_conics, d_values, nullptr, stream));
+    CHECK_PIGS(pigs_plan_build(ws2, pb, sws2, sb, 0, N, M, c, q_max, q_max + 4.f, d_means, d_conics, d_values, nullptr, stream));
     CHECK_PIGS(pigs_plan_forward(ws2, pb, sws2, sb, N, M, c, q_max, 0x1, b0_2, nullptr, nullptr, nullptr, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     {

@@ -111,7 +111,7 @@ def test_residual_equals_composed_outputs_at_c3_size(hip_lib):
     comp = a0 * u + a1[0] * du[:, 0] + a1[1] * du[:, 1] + aL * lap - target
     g_c = torch.autograd.grad((comp * w).sum(), (t["means"], t["values"], t["conics"]))
     scale = float(max(a0 * u.detach().abs().max(), abs(aL) * lap.detach().abs().max()))
-    assert float((r - comp).abs().max()) / scale < 2e-6
+    assert float((r - comp).detach().abs().max()) / scale < 2e-6
     for a, b in zip(g_r, g_c):
         assert float((a - b).abs().max() / b.abs().max()) < 5e-6
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which mechanism is behind the binned path's larger conic-gradient error in the fuzz_big cases:
-the same case through dense, binned(q_max = 36) and binned(q_max = 60) against the float64 oracle on the
+the same case through dense, binned(q_max = 36; backward cut-off 36 / 40 / 44) and binned(q_max = 60) against the float64 oracle on the
 Gaussians where binned and dense differ most.  argv: case index (seed 1 of tools/fuzz_big.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,8 @@ f32 = [a.astype(np.float32) for a in (means, values, con, pts)]
 shapes = {0: (M, c), 1: (M, 2, c), 2: (M, 2, 2, c), "lap": (M, c)}
 rs = {o: rng.uniform(0, 1, shapes[o]).astype(np.float32) for o in orders}
 res = {}
-for name, kw in (("dense", dict(backend="dense")), ("binned36", dict(backend="binned")),
+for name, kw in (("dense", dict(backend="dense")), ("binned36", dict(backend="binned", q_max_backward=36.0)),
+                 ("bwd40", dict(backend="binned", q_max_backward=40.0)), ("bwd44", dict(backend="binned", q_max_backward=44.0)),
                  ("binned60", dict(backend="binned", q_max=60.0))):
     t = [torch.tensor(a, device="cuda") for a in f32]
     for x in t[:3]:
