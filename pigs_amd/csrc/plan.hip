@@ -36,6 +36,15 @@
                               // + L2-bypassing accesses, 70.4 with per-XCD arrival counters -- a device-wide barrier on 8
                               // mutually incoherent L2s costs more than the ~3.7 us of a kernel boundary.  Kept as the record.
 #endif
+#ifndef PIGS_BWD_BLOCK
+#define PIGS_BWD_BLOCK 0      // 1: the backward walks BLOCK lists (one wave = four tiles, one atomic per entry and value for all
+                              // four: 2.2x fewer atomics); 0: tile lists (one wave = one tile).  Measured on one box, C3,
+                              // kappa 0.5, kernel + unpermute, q_b = 36 / 40 / 44: block 92.2 / 97.6 / 103.7 us, tile 76.5 /
+                              // 84.5 / 87.4 -- with gradients at orders 0..2 the kernel is bound by its arithmetic and the
+                              // serial life of its waves, and 4 096 four-tile waves (one generation) overlap worse than
+                              // 16 384 one-tile waves; only the light order-0 backward gains (66 vs 71-76 us).  Kept as the
+                              // record (tests pass with either setting).
+#endif
 #ifndef PIGS_BWD_WAVES
 #define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to (its LDS allows 4 workgroups per CU)
 #endif
@@ -628,6 +637,7 @@ struct ListsLds {
     float4 sb[SURV_CAP];              //           {c, -b/c, -b/a, sorted index (bits)}
     float4 gbox[LISTS_TPW * 4];       // boxes of the groups: {x0, y0, x1, y1}
     uint32_t sel[SURV_CAP];           // positions of the survivors that reach the tile in hand
+    uint32_t bmask[SURV_CAP];         // per survivor: the four tiles' masks, byte t = wide << 4 | narrow
 };
 struct ListArgs {
     PlanView pv;
@@ -683,11 +693,25 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         for (int g = 0; g < 4; ++g) ng[t][g] = 0;
     }
     int sn = 0;
+#if PIGS_BWD_BLOCK
+    // The block list lives in the tile-list slabs of the block's tiles (8-byte entries {sorted index, masks}):
+    // capacity = tiles x cap / 2.
+    uint2* const blist = (uint2*)(a.tlist + (size_t)tile0 * cap);
+    const uint32_t tiles_here = ntiles - tile0 < (uint32_t)LISTS_TPW ? ntiles - tile0 : (uint32_t)LISTS_TPW;
+    const uint32_t cap_b = tiles_here * cap / 2;
+    uint32_t nb = 0;
+    bool boverflow = false;
+#endif
     // the tiles' tests on the survivors in LDS: per tile, (A) the survivors that reach the tile's
     // box, compacted (their positions, one byte each would do: 128 survivors), then (B) the four
     // group tests on those: usually one step of 64 instead of two
     auto flush = [&]() __attribute__((always_inline)) {
         wave_lds_fence();
+#if PIGS_BWD_BLOCK
+        lds.bmask[lane] = 0u;
+        lds.bmask[lane + 64] = 0u;
+        wave_lds_fence();
+#endif
 #pragma unroll
         for (int t = 0; t < LISTS_TPW; ++t) {
             if (tile0 + (uint32_t)t >= ntiles) continue;
@@ -731,11 +755,16 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
                 if (s0 + lane >= sel) gm = gf = 0u;
                 const uint64_t km = __ballot(gm != 0u);
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
+#if PIGS_BWD_BLOCK
+                (void)tl;
+                if (gm != 0u) lds.bmask[k] |= ((gm << 4) | gf) << (8 * t);      // one lane per survivor k in this pass
+#else
                 if (n[t] + cnt <= cap) {
                     if (gm != 0u) tl[n[t] + (uint32_t)lanes_below(km)] = j | (gm << LIST_WIDE_SHIFT) | (gf << LIST_NARROW_SHIFT);
                 } else {
                     overflow[t] = true;
                 }
+#endif
                 n[t] += cnt;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -751,6 +780,22 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
             }
             wave_lds_fence();
         }
+#if PIGS_BWD_BLOCK
+        // the block list: every survivor that reaches a group of any of the four tiles, once, with all its masks
+        for (int s0 = 0; s0 < sn; s0 += 64) {
+            const int k = s0 + lane;
+            const uint32_t bm = k < sn ? lds.bmask[k] : 0u;
+            const uint64_t km = __ballot(bm != 0u);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(km);
+            if (nb + cnt <= cap_b) {
+                if (bm != 0u) blist[nb + (uint32_t)lanes_below(km)] = make_uint2(__builtin_bit_cast(uint32_t, lds.sb[k].w), bm);
+            } else {
+                boverflow = true;
+            }
+            nb += cnt;
+        }
+        wave_lds_fence();
+#endif
         sn = 0;
     };
     traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.trav, true,
@@ -774,6 +819,17 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     const bool two_cuts = pv.q_max > a.q_f;
     bool any_rare = false;
     bool rebuild[LISTS_TPW];
+#if PIGS_BWD_BLOCK
+    // The block list serves the backward of all four tiles when it fits and every group list (the forward's) does;
+    // otherwise (very wide Gaussians, scattered points) the tiles fall back one by one: group lists only
+    // (rebuilt with the wide cut-off: the backward then walks those) or record ranges.
+    bool block_ok = !boverflow;
+#pragma unroll
+    for (int t = 0; t < LISTS_TPW; ++t) block_ok = block_ok && !(tile0 + (uint32_t)t < ntiles && goverflow[t]);
+    if (lane == 0) a.hdr[(size_t)tile0 * TILE_HDR_WORDS + 5] = block_ok ? (nb | 0x80000000u) : 0u;
+#pragma unroll
+    for (int t = 0; t < LISTS_TPW; ++t) overflow[t] = !block_ok;      // as if every tile list had overflowed
+#endif
 #pragma unroll
     for (int t = 0; t < LISTS_TPW; ++t) {
         rebuild[t] = false;
@@ -783,13 +839,17 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         rebuild[t] = tl_over && !goverflow[t] && two_cuts;
         any_rare |= overflow[t] || rebuild[t];
         if (!overflow[t] && !rebuild[t] && lane < TILE_HDR_WORDS) {
+#if PIGS_BWD_BLOCK
+            const bool fits = block_ok;      // LIST here = "its block list is valid" (n[t]: the tile's own entries, for statistics)
+#else
             const bool fits = n[t] <= cap;
+#endif
             uint32_t w = 0;
-            if (lane == 0) w = fits ? (n[t] | (TILE_MODE_LIST << TILE_MODE_SHIFT)) : (TILE_MODE_GROUPS << TILE_MODE_SHIFT);
+            if (lane == 0) w = fits ? ((n[t] & TILE_COUNT_MASK) | (TILE_MODE_LIST << TILE_MODE_SHIFT)) : (TILE_MODE_GROUPS << TILE_MODE_SHIFT);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (lane == 1 + g) w = ng[t][g];
-            a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = w;
+            if (lane < 5) a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = w;      // words 5..7: the block's
         }
     }
     if (!any_rare) return;
@@ -841,7 +901,7 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
                 }
             });
             if (!gover) {
-                if (lane < TILE_HDR_WORDS) {
+                if (lane < 5) {
                     uint32_t w = 0;
                     if (lane == 0) w = TILE_MODE_GROUPS << TILE_MODE_SHIFT;
 #pragma unroll
@@ -873,7 +933,7 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
                  [](const float4, const float4, uint64_t, uint32_t) {});
         if (!fits && lane == 0) { tl[0] = 0; tl[1] = pv.N; }
         const uint32_t cnt = fits ? nr : 1u;
-        if (lane < TILE_HDR_WORDS)
+        if (lane < 5)
             a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (cnt | (TILE_MODE_RANGES << TILE_MODE_SHIFT)) : 0u;
     }
 }
@@ -1351,28 +1411,18 @@ constexpr int bwd_waves() {
     // the widest gradient sets either); c = 1 with order 3 the same for its registers
     return (C == 2 || MASK == 15) ? 3 : (MASK == 7 || MASK == 19 || MASK == ORDR || MASK == 1 || MASK == 2) ? PIGS_BWD_WAVES : 4;
 }
+// this lane's point of a tile and the gradients that arrive at it (lanes behind the last point: zero)
 template <int C, int MASK>
-__global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
-    PlanView pv, SamplesView sv, const float* __restrict__ G0p, const float* __restrict__ G1p,
-    const float* __restrict__ G2p, const float* __restrict__ G3p, Resid<float> rz) {
-    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;      // a residual's backward = orders 0, 1, trace
-    using BL = BwdLayout<2, C>;
-    constexpr int NV = BL::N;
-    constexpr int S = TileLdsBwd<NV>::S;
-    __shared__ TileLdsBwd<NV> lds_all[4];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = spread_tile(xcd_block() * 4 + (uint32_t)wave, sv.ntiles);
-    if (tile >= sv.ntiles) return;
-    TileLdsBwd<NV>& lds = lds_all[wave];
+__device__ __forceinline__ void load_tile_point(const SamplesView& sv, uint32_t tile, int lane, const float* __restrict__ G0p,
+                                                const float* __restrict__ G1p, const float* __restrict__ G2p,
+                                                const float* __restrict__ G3p, const Resid<float>& rz, SPoint& sp, bool& valid,
+                                                Gsym<float, 2, C, (MASK == ORDR ? ORDR_AS : MASK)>& G) {
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
-    const bool valid = m < sv.M;
-    const SPoint sp = sv.spts[valid ? m : sv.M - 1];
-    const float s[2] = {sp.x, sp.y};
-    Gsym<float, 2, C, EM> G;
+    valid = m < sv.M;
+    sp = sv.spts[valid ? m : sv.M - 1];
     if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
     else G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
-    if (!valid) {               // lanes behind the last point contribute nothing
+    if (!valid) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
             G.g0[ch] = 0.f;
@@ -1381,6 +1431,23 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
             G.g3[0][ch] = G.g3[1][ch] = G.g3[2][ch] = G.g3[3][ch] = 0.f;
         }
     }
+}
+
+// one tile through its own lists (tile list / group lists / record ranges)
+template <int C, int MASK>
+__device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesView& sv, uint32_t tile,
+                                              TileLdsBwd<BwdLayout<2, C>::N>& lds, int lane, const float* __restrict__ G0p,
+                                              const float* __restrict__ G1p, const float* __restrict__ G2p,
+                                              const float* __restrict__ G3p, const Resid<float>& rz) {
+    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;      // a residual's backward = orders 0, 1, trace
+    using BL = BwdLayout<2, C>;
+    constexpr int NV = BL::N;
+    constexpr int S = TileLdsBwd<NV>::S;
+    SPoint sp;
+    bool valid;
+    Gsym<float, 2, C, EM> G;
+    load_tile_point<C, MASK>(sv, tile, lane, G0p, G1p, G2p, G3p, rz, sp, valid, G);
+    const float s[2] = {sp.x, sp.y};
     if (lane < 2) lds.t.rec[BWD_STEP][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     // A tile that fell back to record ranges has no masks: they are found entry by entry against the
     // boxes of its four groups (a range holds every Gaussian NEAR the tile; few reach a given group when
@@ -1439,6 +1506,125 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
             for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], sum[q]);
         }
     }, ranges_mask);
+}
+
+template <int C, int MASK>
+__global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
+    PlanView pv, SamplesView sv, const float* __restrict__ G0p, const float* __restrict__ G1p,
+    const float* __restrict__ G2p, const float* __restrict__ G3p, Resid<float> rz) {
+    __shared__ TileLdsBwd<BwdLayout<2, C>::N> lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = spread_tile(xcd_block() * 4 + (uint32_t)wave, sv.ntiles);
+    if (tile >= sv.ntiles) return;
+    backward_tile<C, MASK>(pv, sv, tile, lds_all[wave], lane, G0p, G1p, G2p, G3p, rz);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward over BLOCK lists: one wave = one block of four consecutive tiles (256 consecutive sorted points:
+// a 16 x 16 patch of a grid), the unit the list build walks the grid for.  Neighbouring tiles share most of
+// their Gaussians (a block's list holds ~1.9x what one tile's does, not 4x), and what bounds the tile-by-
+// tile backward beside its arithmetic is the L2's atomic rate (one cache-line operation per ~40 ps
+// chip-wide; a tile's entries touch ~12 lines per value): here an entry's sums over all four tiles are
+// added up in the lane's registers and leave as ONE atomic per entry and value.  A step = 64 entries of the
+// block list (records to LDS once); for each of the four tiles: its point and incoming gradients, the
+// entries' masks for this tile split into the four per-row lists, the rows (as in backward_tile), the
+// lane's rows of the sums table added to its registers.
+// ------------------------------------------------------------------------------------------
+template <int C, int MASK>
+__global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void block_backward_kernel(
+    PlanView pv, SamplesView sv, const float* __restrict__ G0p, const float* __restrict__ G1p,
+    const float* __restrict__ G2p, const float* __restrict__ G3p, Resid<float> rz) {
+    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;
+    using BL = BwdLayout<2, C>;
+    constexpr int NV = BL::N;
+    constexpr int S = TileLdsBwd<NV>::S;
+    constexpr bool WIDE = (EM & (ORD2 | ORD3 | ORD2T)) != 0;
+    __shared__ TileLdsBwd<NV> lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nblocks = (sv.ntiles + 3u) / 4u;
+    // the same strips of the domain on the same XCD as the list build's; inside an XCD's chunk of 256 blocks the
+    // blocks that run together are dealt apart (neighbours flush the same lines at the same moment: spread_tile)
+    uint32_t block = xcd_block_chunk<PIGS_XCD_CHUNK / 4>() * 4 + (uint32_t)wave;
+    if (block >= nblocks) return;
+    {
+        const uint32_t base = block & ~255u;
+        if (PIGS_BWD_SPREAD != 0 && base + 256u <= nblocks) block = base + ((block & 255u) * 37u & 255u);
+    }
+    TileLdsBwd<NV>& lds = lds_all[wave];
+    const uint32_t tile0 = block * 4;
+    const uint32_t bh = pv.hdr[(size_t)tile0 * TILE_HDR_WORDS + 5];
+    if (!(bh >> 31)) {                       // no block list (very wide Gaussians, scattered points): tile by tile
+        for (uint32_t t = 0; t < 4 && tile0 + t < sv.ntiles; ++t)
+            backward_tile<C, MASK>(pv, sv, tile0 + t, lds, lane, G0p, G1p, G2p, G3p, rz);
+        return;
+    }
+    const uint32_t nb = bh & 0x7fffffffu;
+    const uint2* blist = (const uint2*)(pv.tlist + (size_t)tile0 * pv.list_cap);
+    if (lane < 2) lds.t.rec[BWD_STEP][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the four tiles' points and incoming gradients stay in registers for the whole block (4 x 10 VGPRs; the
+    // kernel's occupancy is set by its LDS): loaded once, all in flight together
+    // -- where they are few (one channel, orders up to 2); the wide gradient sets (two channels, third
+    // derivatives: up to 20 values per tile) are fetched again for every (step, tile) instead of spilling
+    constexpr bool KEEP = FwdLayout<2, C, EM>::N <= 7;
+    constexpr int NK = KEEP ? 4 : 1;
+    SPoint sp[NK];
+    bool valid[NK];
+    Gsym<float, 2, C, EM> G[NK];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t tt = tile0 + (uint32_t)t < sv.ntiles ? tile0 + (uint32_t)t : tile0;      // a ragged last block repeats tile 0 (its masks are zero)
+            load_tile_point<C, MASK>(sv, tt, lane, G0p, G1p, G2p, G3p, rz, sp[t], valid[t], G[t]);
+        }
+    }
+    for (uint32_t e0 = 0; e0 < nb; e0 += BWD_STEP) {
+        const bool have = lane < BWD_STEP && e0 + (uint32_t)lane < nb;
+        const uint2 ent = have ? blist[e0 + lane] : make_uint2(0u, 0u);
+        const uint32_t idx = ent.x;
+        const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
+        wave_lds_fence();
+        if (lane < BWD_STEP) {
+            lds.t.rec[lane][0] = A;
+            lds.t.rec[lane][1] = B;
+        }
+        float sum[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) sum[q] = 0.f;
+        uint32_t any = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t byte = ent.y >> (8 * t) & 0xffu;
+            const uint32_t gm = WIDE ? byte >> 4 : byte & 15u;
+            if (__ballot(gm != 0u) == 0ull) continue;         // no entry of this step reaches this tile
+            const int tk = KEEP ? t : 0;
+            if constexpr (!KEEP) load_tile_point<C, MASK>(sv, tile0 + (uint32_t)t, lane, G0p, G1p, G2p, G3p, rz, sp[0], valid[0], G[0]);
+            const float s[2] = {sp[tk].x, sp[tk].y};
+            int rank[4];
+            wave_lds_fence();
+            const int rows = split_step<4>(lds.t, gm, lane, rank);
+            wave_lds_fence();
+            backward_rows<C, EM>(s, G[tk], lds, rows, lane);
+            wave_lds_fence();
+            any |= gm;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (gm >> g & 1u) {
+                    const float2* src = (const float2*)lds.sums[g][rank[g]];
+#pragma unroll
+                    for (int q = 0; q < S; q += 2) {
+                        const float2 v = src[q / 2];
+                        sum[q] += v.x; sum[q + 1] += v.y;
+                    }
+                }
+            }
+        }
+        if (have && any != 0u) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], sum[q]);
+        }
+    }
 }
 
 template <int C>
@@ -1675,10 +1861,18 @@ static int plan_backward_c(const PlanView& pv, const SamplesView& sv, int mask, 
                            float* gc, float* gv, hipStream_t stream, const Resid<float>& rz) {
     const dim3 grid((sv.ntiles + 3) / 4), block(256);
     clear_hip_error();
+#if PIGS_BWD_BLOCK
+    const dim3 bgrid((((sv.ntiles + 3) / 4) + 3) / 4);
+#define PIGS_CASE(MK)                                                                                             \
+    case MK:                                                                                                      \
+        hipLaunchKernelGGL((block_backward_kernel<C, MK>), bgrid, block, 0, stream, pv, sv, g[0], g[1], g[2], g[3], rz); \
+        break;
+#else
 #define PIGS_CASE(MK)                                                                                             \
     case MK:                                                                                                      \
         hipLaunchKernelGGL((tile_backward_kernel<C, MK>), grid, block, 0, stream, pv, sv, g[0], g[1], g[2], g[3], rz); \
         break;
+#endif
     switch (mask) {
         PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19) PIGS_CASE(32)
         default: return PIGS_ERR_UNSUPPORTED;
