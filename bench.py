@@ -61,7 +61,7 @@ def parse():
     return ap.parse_args()
 
 
-def measured_traffic(workload, kappa, binned):
+def measured_traffic(workload, kappa, binned, which="forward"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, corrected
     as MI355X_MICROARCH.md 'HBM' prescribes).  The record names the source hash of the library it was
@@ -77,6 +77,10 @@ def measured_traffic(workload, kappa, binned):
             return None, f"no PMC profile committed for {key}"
         if rec.get("source_hash") != B.source_hash():
             return None, f"profiles/pmc_traffic.json[{key}] was measured on other kernel sources (hash mismatch)"
+        if which == "backward":
+            if "backward" not in rec:
+                return None, f"profiles/pmc_traffic.json[{key}] holds no backward record"
+            return rec["backward"].get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json[{key}].backward @ source {rec['source_hash'][:12]}"
         return rec.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json[{key}] @ source {rec['source_hash'][:12]}"
     except (OSError, ValueError, KeyError) as e:
         return None, f"{type(e).__name__}: {e}"
@@ -504,8 +508,10 @@ def main():
             go = [torch.randn((M,) + (2,) * k + (1,), device=dev) for k in range(3)] + [None, None]
             kb_ms = kernel_ms(lambda: S.backward_raw(means, values, conics, samples, go, 7, plan), max(5, nb))
         bwd_bytes = 48 * N + 36 * M
+        btraffic, bsource = measured_traffic(a.workload, a.kappa, plan is not None, "backward")
         roofline_bwd = {"bound": "hbm", "achieved": bwd_bytes / (kb_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": bwd_bytes / (kb_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                        "unit": "GB/s", "frac": bwd_bytes / (kb_ms * 1e-3) / HBM_PEAK, "traffic": btraffic,
+                        "traffic_source": bsource, "q_max_backward": sampler_w.q_max_backward,
                         "kernel": ("tile_backward_kernel<1,7> + plan_unpermute_kernel<1>" if plan is not None
                                    else "dense_backward_kernel"),
                         "kernel_ms": kb_ms, "algorithmic_bytes": bwd_bytes}

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Fold rocprofv3 PMC passes of the forward launch into profiles/pmc_traffic.json.
+"""Fold rocprofv3 PMC passes of the forward (and backward) launch into profiles/pmc_traffic.json.
 
 On the GPU box (each counter set in its own run, kernel trace only -- never with sys/hip traces):
     tools/pmc_run.sh fetch  "FETCH_SIZE"               fwd --steps 20 [--kappa K]
     tools/pmc_run.sh write  "WRITE_SIZE"               fwd --steps 20 [--kappa K]
     tools/pmc_run.sh hit    "TCC_HIT_sum TCC_MISS_sum" fwd --steps 20 [--kappa K]
     tools/pmc_run.sh sq     "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" fwd --steps 20
+    (the same four with `bwd` instead of `fwd` for the backward launch: tags bfetch, bwrite, bhit, bsq)
 then here:  python tools/pmc_collect.py gpurun_out/pmc_fetch gpurun_out/pmc_write ... [--key c3:kappa=0.5:binned]
 Units: FETCH_SIZE / WRITE_SIZE are KiB (MI355X_MICROARCH.md "HBM"); on gfx950 FETCH_SIZE counts wide
 reads at half their size, so the corrected figure is (2 x FETCH_SIZE + WRITE_SIZE) KiB.
@@ -52,6 +53,21 @@ table[key] = {
            "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB is the corrected upper figure, hbm_bytes_raw the "
            "uncorrected one.",
 }
-table["all_kernels"] = {**table.get("all_kernels", {}), **allk}
+bw = next((v for k, v in allk.items() if "tile_backward_kernel<1, 7>" in k), None)
+un = next((v for k, v in allk.items() if "plan_unpermute_kernel<1>" in k), None)
+if bw is not None and "FETCH_SIZE" in bw and "WRITE_SIZE" in bw:
+    un = un or {}
+    table[key]["backward"] = {
+        "kernel": "tile_backward_kernel<1,7> + plan_unpermute_kernel<1>",
+        "FETCH_SIZE_KiB": bw["FETCH_SIZE"] + un.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": bw["WRITE_SIZE"] + un.get("WRITE_SIZE", 0.0),
+        "hbm_bytes_per_launch": (2 * (bw["FETCH_SIZE"] + un.get("FETCH_SIZE", 0.0)) + bw["WRITE_SIZE"] + un.get("WRITE_SIZE", 0.0)) * 1024,
+        "algorithmic_bytes": 48 * N + 36 * M,
+        "TCC_HIT_sum": bw.get("TCC_HIT_sum"), "TCC_MISS_sum": bw.get("TCC_MISS_sum"),
+        "SQ": {c: v for c, v in bw.items() if c.startswith("SQ_")},
+        "how": "the same passes over `tools/prof_step.py bwd --steps 20` (the backward launches alone on one plan); both kernels "
+               "of the backward summed; same units and gfx950 correction as the forward record",
+    }
+# only the kernels of THIS collection (records of earlier rounds' kernels do not linger)
+table["all_kernels"] = allk
 json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(table[key], indent=1))

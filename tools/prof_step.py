@@ -38,7 +38,7 @@ def list_stats(plan):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", nargs="?", default="cold", choices=["cold", "warm", "fwd", "fwdbwd"])
+    ap.add_argument("mode", nargs="?", default="cold", choices=["cold", "warm", "fwd", "bwd", "fwdbwd"])
     ap.add_argument("--kappa", type=float, default=0.5)
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--lat", type=int, default=256)
@@ -67,14 +67,19 @@ def main():
             torch.autograd.grad(outs, list(req.values()), grad_outputs=gouts)
         elif a.mode == "fwd":
             S.forward_raw(*s._inputs, 7, s._plan)
+        elif a.mode == "bwd":
+            S.backward_raw(*s._inputs, bw_gouts, 7, s._plan)
         else:
             with torch.no_grad():
                 s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
                 s.sample((0, 1, 2))
 
-    if a.mode == "fwd":
+    bw_gouts = None
+    if a.mode in ("fwd", "bwd"):
         with torch.no_grad():
             s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts)
+            M = pts.shape[0]
+            bw_gouts = [torch.randn((M,) + (2,) * k + (1,), device=dev) for k in range(3)] + [None, None]
     for _ in range(20):
         step()
     torch.cuda.synchronize()
