@@ -96,8 +96,8 @@ def plan_rows(plan):
         return None
     ntiles, off_hdr = info[0], info[2]
     hdr = plan.workspace[off_hdr:off_hdr + 32 * ntiles].view(torch.int32).reshape(ntiles, 8)
-    if int(((hdr[:, 0] >> 30) & 3).eq(1).sum()) != 0:
-        return None                       # range-mode tiles: the headers do not hold the row count
+    if int(((hdr[:, 0] >> 30) & 1).sum()) != 0:
+        return None                       # range-mode / point-mode tiles: the headers do not hold the row count
     ng = hdr[:, 1:5].to(torch.int64)
     wave_rows = int(((ng.max(dim=1).values + 1) // 2 * 2).sum())
     return {"wave_rows": wave_rows, "pairs": int(ng.sum()) * 16}

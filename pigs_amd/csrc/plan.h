@@ -74,7 +74,24 @@ constexpr int LIST_WIDE_SHIFT = 24, LIST_NARROW_SHIFT = 28;
 // tile header, 8 words: [0] = count | mode << 30 (entries of the tile list, or record ranges), [1..4] =
 // lengths of the four group lists (list mode)
 constexpr int TILE_HDR_WORDS = 8;
-constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u, TILE_MODE_GROUPS = 2u;
+constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u, TILE_MODE_GROUPS = 2u, TILE_MODE_POINTS = 3u;
+// TILE_MODE_POINTS: a tile of points so far apart (the thin outskirts of a clustered cloud) that even its
+// 16-point groups meet more Gaussians than a list holds although every single point meets few: no lists
+// at all -- at sampling time the Gaussian grid is walked around every single point (the 3 x 3 cells of every
+// occupied level) by HELPER workgroups behind the main ones of the same launch: the list build queues such
+// tiles (PlanParams::n_points, `ptiles`), a helper wave takes four points at a time, 16 lanes per point
+// (lane = candidate), so the few tiles of this kind spread over POINT_HELPER_BLOCKS x 4 waves instead of
+// sitting in one wave each for the length of ~150 dependent loads per lane.  Chosen when the tile's box spans more than
+// POINTS_MODE_MIN_CELLS finest Gaussian cells (the points are spread out; close points under wide Gaussians
+// keep their lists / record ranges: the walk would meet more candidates than the lists hold) and its longest
+// group list exceeds POINTS_MODE_MIN_LIST entries (a walk costs about that much: ~9 cells x a few Gaussians
+// x the occupied levels of candidates per point) or does not fit at all -- provided the walk itself stays
+// small (9 cells of every level at the level's mean occupancy <= 4 x the list length: very wide Gaussians sit
+// in coarse levels whose 3 x 3 cells are most of the plan).
+constexpr float POINTS_MODE_MIN_CELLS = 16.f;
+constexpr uint32_t POINTS_MODE_MIN_LIST = 96u;
+constexpr uint32_t POINT_HELPER_BLOCKS = 64u;
+constexpr float POINTS_MODE_BLOCK_CELLS = 256.f;      // a 256-point block spread over more cells than this is not listed at all
 constexpr int TILE_MODE_SHIFT = 30;
 constexpr uint32_t TILE_COUNT_MASK = (1u << TILE_MODE_SHIFT) - 1u;
 
@@ -107,6 +124,7 @@ struct PlanParams {
     uint32_t scan_error;
     float q_f, q_b;        // the plan's two cut-offs (forward / backward of order >= 2 gradients), q_b >= q_f
     uint32_t bar[PLAN_BAR_WORDS];   // device-wide barriers of the one-launch Gaussian chain (zero between builds)
+    uint32_t n_points;              // tiles in TILE_MODE_POINTS (queued in `ptiles` by the list build)
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -154,7 +172,7 @@ struct PlanLayout {
     uint32_t ntiles;           // ceil(M / 64)
     uint32_t list_cap;         // entries per list slab (one tile list + four group lists per tile), multiple of 16
     size_t off_params, off_counts, off_agg, off_starts, off_gkey, off_rec, off_box, off_g2o, off_gacc, off_hdr,
-        off_tlist, off_glist, total_bytes;
+        off_ptiles, off_tlist, off_glist, total_bytes;
 };
 
 // Counter spacing of a level with `cells` cells: device-scope atomics on one 128-byte line
@@ -208,6 +226,7 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
     p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [8][N]
     p.off_hdr = o;      o = align_up(o + sizeof(uint32_t) * TILE_HDR_WORDS * (size_t)p.ntiles, 256);
+    p.off_ptiles = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles, 256);           // queue of the TILE_MODE_POINTS tiles
     p.off_tlist = o;    o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles * p.list_cap, 256);
     p.off_glist = o;    o = align_up(o + sizeof(uint32_t) * 4 * (size_t)p.ntiles * p.list_cap, 256);
     p.total_bytes = o;
@@ -231,6 +250,7 @@ struct PlanView {
     const uint32_t* hdr;          // [ntiles][TILE_HDR_WORDS]
     const uint32_t* tlist;        // [ntiles][list_cap]     tile lists (entries with group masks) / record ranges
     const uint32_t* glist;        // [ntiles][4][list_cap]  group lists (sorted Gaussian indices)
+    const uint32_t* ptiles;       // [params->n_points]     the tiles in TILE_MODE_POINTS
     uint32_t N, list_cap;
     int G0, L;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             a.params->scan_error = 0;
             a.params->q_f = a.q_f;
             a.params->q_b = a.q_b;
+            a.params->n_points = 0u;
 #pragma unroll
             for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
         }
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
         a.params->scan_error = 0;
         a.params->q_f = a.q_f;
         a.params->q_b = a.q_b;
+        a.params->n_points = 0u;
 #pragma unroll
         for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
     }
@@ -575,17 +577,17 @@ __global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
 #define PIGS_XCD_CHUNK 256
 #endif
 template <uint32_t CHUNK>
-__device__ __forceinline__ uint32_t xcd_block_chunk() {
+__device__ __forceinline__ uint32_t xcd_block_chunk(uint32_t nblocks) {      // nblocks: the blocks that take part (helpers behind them keep out)
     if constexpr (CHUNK > 0) {
         constexpr uint32_t GROUP = 8u * CHUNK;
         const uint32_t b = blockIdx.x, g = b / GROUP, r = b % GROUP;
-        if ((g + 1) * GROUP > gridDim.x) return b;
+        if ((g + 1) * GROUP > nblocks) return b;
         return g * GROUP + (r & 7u) * CHUNK + (r >> 3);
     } else {
         return blockIdx.x;
     }
 }
-__device__ __forceinline__ uint32_t xcd_block() { return xcd_block_chunk<PIGS_XCD_CHUNK>(); }
+__device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) { return xcd_block_chunk<PIGS_XCD_CHUNK>(nblocks); }
 
 // Bounding boxes with the DPP modifier fused into the min / max (hipcc emits v_mov_dpp + a
 // canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  The four
@@ -645,6 +647,8 @@ struct ListArgs {
     uint32_t* hdr;
     uint32_t* tlist;
     uint32_t* glist;
+    uint32_t* ptiles;     // queue of the tiles in TILE_MODE_POINTS
+    uint32_t* n_points;   //   and its length (PlanParams::n_points, zeroed by the count kernel)
     float q_f;            // the narrow cut-off (pv.q_max is the wide one)
 };
 
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the same strips of the domain on the same XCD as in the sampling kernels, which then find a tile's
     // lists in the L2 that wrote them (a workgroup here is 4 * LISTS_TPW tiles; forward 27.05 -> 26.4 us)
-    const uint32_t tile0 = (xcd_block_chunk<PIGS_XCD_CHUNK / LISTS_TPW>() * 4 + (uint32_t)wave) * LISTS_TPW;
+    const uint32_t tile0 = (xcd_block_chunk<PIGS_XCD_CHUNK / LISTS_TPW>(gridDim.x) * 4 + (uint32_t)wave) * LISTS_TPW;
     const uint32_t ntiles = a.sv.ntiles;
     if (tile0 >= ntiles) return;
     ListsLds& lds = lds_all[wave];
@@ -684,6 +688,30 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     wave_box_from_rows_dpp(bx0, bx1, by0, by1);
 
     const uint32_t cap = pv.list_cap;
+    // what a per-point walk would meet: 9 cells of every level at the level's mean occupancy (wave-uniform;
+    // all lanes call it together)
+    auto walk_candidates = [&]() -> float {
+        float e = 0.f;
+        if (lane < pv.L) {
+            const float cells = (float)(pv.G0 >> lane) * (float)(pv.G0 >> lane);
+            e = 9.f * (float)(pv.starts[pv.level_off[lane + 1]] - pv.starts[pv.level_off[lane]]) / cells;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) e += __shfl_xor(e, o);      // levels live in lanes 0..11
+        return __shfl(e, 0);
+    };
+    // A block of 256 points spread over more than POINTS_MODE_BLOCK_CELLS finest Gaussian cells (a group of 16 then
+    // spans dozens of cells: its list would run to hundreds) goes to the per-point walk without being listed at
+    // all: the traversal of such a box is the list build's own tail (thousands of candidates in one wave).
+    if ((bx1 - bx0) * gg.inv_s0 * ((by1 - by0) * gg.inv_s0) > POINTS_MODE_BLOCK_CELLS && walk_candidates() <= 4.f * (float)cap) {
+        for (int t = 0; t < LISTS_TPW; ++t) {
+            if (tile0 + (uint32_t)t >= ntiles) break;
+            if (lane < TILE_HDR_WORDS)
+                a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (TILE_MODE_POINTS << TILE_MODE_SHIFT) : 0u;
+            if (lane == 0) a.ptiles[atomicAdd(a.n_points, 1u)] = tile0 + (uint32_t)t;
+        }
+        return;
+    }
     uint32_t n[LISTS_TPW], ng[LISTS_TPW][4];
     bool overflow[LISTS_TPW], goverflow[LISTS_TPW];       // the tile list / one of the group lists is full
 #pragma unroll
@@ -837,6 +865,24 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
         const bool tl_over = overflow[t];
         overflow[t] = tl_over && goverflow[t];            // from here on: the tile needs the ranges fallback
         rebuild[t] = tl_over && !goverflow[t] && two_cuts;
+        // spread-out points with long lists: the per-point walk is cheaper than the lists (plan.h)
+        uint32_t longest = ng[t][0] > ng[t][1] ? ng[t][0] : ng[t][1];
+        longest = ng[t][2] > longest ? ng[t][2] : longest;
+        longest = ng[t][3] > longest ? ng[t][3] : longest;
+        if (longest > POINTS_MODE_MIN_LIST) {
+            float4 gb[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gb[g] = lds.gbox[t * 4 + g];
+            const float wx = fmaxf(fmaxf(gb[0].z, gb[1].z), fmaxf(gb[2].z, gb[3].z)) - fminf(fminf(gb[0].x, gb[1].x), fminf(gb[2].x, gb[3].x));
+            const float wy = fmaxf(fmaxf(gb[0].w, gb[1].w), fmaxf(gb[2].w, gb[3].w)) - fminf(fminf(gb[0].y, gb[1].y), fminf(gb[2].y, gb[3].y));
+            if (wx * gg.inv_s0 * (wy * gg.inv_s0) > POINTS_MODE_MIN_CELLS && walk_candidates() <= 4.f * (float)(longest < cap ? longest : cap)) {
+                overflow[t] = false; rebuild[t] = false;
+                if (lane < 5)
+                    a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (TILE_MODE_POINTS << TILE_MODE_SHIFT) : 0u;
+                if (lane == 0) a.ptiles[atomicAdd(a.n_points, 1u)] = tile0 + (uint32_t)t;
+                continue;
+            }
+        }
         any_rare |= overflow[t] || rebuild[t];
         if (!overflow[t] && !rebuild[t] && lane < TILE_HDR_WORDS) {
 #if PIGS_BWD_BLOCK
@@ -913,6 +959,14 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
             }
             mine = true;          // the wide group lists do not fit either: ranges
         }
+        // scattered points (a box of many Gaussian cells for 64 points): no lists, every lane walks the grid
+        // around its own point at sampling time (plan.h, TILE_MODE_POINTS)
+        if ((tx1 - tx0) * gg.inv_s0 * ((ty1 - ty0) * gg.inv_s0) > POINTS_MODE_MIN_CELLS && walk_candidates() <= 4.f * (float)cap) {
+            if (lane < 5)
+                a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (TILE_MODE_POINTS << TILE_MODE_SHIFT) : 0u;
+            if (lane == 0) a.ptiles[atomicAdd(a.n_points, 1u)] = tile0 + (uint32_t)t;
+            continue;
+        }
         uint32_t nr = 0;
         bool fits = true;
         traverse(pv, gg, level_mask, loff, tx0, ty0, tx1, ty1, lane, lds.trav, false,
@@ -944,6 +998,38 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
 struct Rec {
     float mu[2], con[3], v[2];
 };
+
+// TILE_MODE_POINTS: this lane's own walk of the Gaussian grid around the point (x, y): in every occupied
+// level the 3 x 3 cells around the point's cell hold every Gaussian of that level whose q <= cut ellipse can
+// contain the point (a Gaussian lives in the lowest level whose cell side covers its ellipse's half extent;
+// out-of-domain coordinates clamp the same monotone way the build binned them).  `body(j, A, B)` gets the
+// sorted index and the record of every candidate; lanes run their own trip counts.
+template <int STRIDE, typename Body>      // the lanes i = 0 .. STRIDE-1 of a point share its candidates: lane i takes j0 + i, j0 + i + STRIDE, ...
+__device__ __forceinline__ void walk_point(const PlanView& pv, float x, float y, int i, Body&& body) {
+    const GaussGrid gg = pv.params->gg;
+    const uint32_t level_mask = pv.params->level_mask;
+    for (int l = 0; l < pv.L; ++l) {
+        if (!(level_mask >> l & 1u)) continue;
+        const int G = pv.G0 >> l;
+        const float inv_s = gg.inv_s0 * __builtin_amdgcn_ldexpf(1.f, -l);
+        const float gmax = (float)(G - 1);
+        const int cx = (int)clampf(floorf((x - gg.ox) * inv_s), 0.f, gmax);
+        const int cy = (int)clampf(floorf((y - gg.oy) * inv_s), 0.f, gmax);
+        const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx < G - 1 ? cx + 1 : G - 1;
+        const int cy0 = cy > 0 ? cy - 1 : 0, cy1 = cy < G - 1 ? cy + 1 : G - 1;
+        const int csh = level_shift((uint32_t)(G * G));
+        for (int yy = cy0; yy <= cy1; ++yy) {
+            const uint32_t row = (uint32_t)(yy * G);
+            const uint32_t j0 = pv.starts[pv.level_off[l] + ((row + (uint32_t)cx0) << csh)];
+            const uint32_t j1 = pv.starts[pv.level_off[l] + ((row + (uint32_t)cx1 + 1u) << csh)];
+            for (uint32_t j = j0 + (uint32_t)i; j < j1; j += STRIDE) body(j, pv.rec[2 * (size_t)j], pv.rec[2 * (size_t)j + 1]);
+        }
+    }
+}
+__device__ __forceinline__ float pair_q(const float4 A, const float4 B, float x, float y) {
+    const float dx = x - A.x, dy = y - A.y;
+    return A.z * dx * dx + (2.f * A.w * dx + B.x * dy) * dy;
+}
 __device__ __forceinline__ Rec make_rec(const float4 A, const float4 B) {
     Rec r;
     r.mu[0] = A.x; r.mu[1] = A.y; r.con[0] = A.z; r.con[1] = A.w; r.con[2] = B.x;
@@ -1099,7 +1185,39 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
     __shared__ FwdLds lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = xcd_block() * 4 + (uint32_t)wave;
+    const uint32_t nmain = (sv.ntiles + 3u) / 4u;
+    if (blockIdx.x >= nmain) {
+        // helper workgroups (plan.h, TILE_MODE_POINTS): four points at a time, 16 lanes per point, lane = candidate
+        const uint32_t n = pv.params->n_points;
+        if (n == 0u) return;
+        const float q_f = pv.params->q_f;
+        const int row = lane >> 4, i = lane & 15;
+        const uint32_t hw = (blockIdx.x - nmain) * 4u + (uint32_t)wave, nhw = (gridDim.x - nmain) * 4u;
+        for (uint32_t qd = hw; qd < n * 16u; qd += nhw) {
+            const uint32_t m = pv.ptiles[qd >> 4] * TILE_POINTS + (qd & 15u) * 4u + (uint32_t)row;
+            const bool valid = m < sv.M;
+            const SPoint sp = sv.spts[valid ? m : sv.M - 1];
+            const float s[2] = {sp.x, sp.y};
+            float acc[L::N];
+#pragma unroll
+            for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
+            // !(q > cut): a degenerate conic (NaN) is evaluated, as the list build's tests would have kept it
+            walk_point<16>(pv, sp.x, sp.y, i, [&](uint32_t, const float4 A, const float4 B) {
+                if (!(pair_q(A, B, sp.x, sp.y) > q_f)) {
+                    const Rec r = make_rec(A, B);
+                    fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v, &rz);
+                }
+            });
+#pragma unroll
+            for (int k = 0; k < L::N; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
+            }
+            if (i == 0 && valid) fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
+        }
+        return;
+    }
+    const uint32_t tile = xcd_block(nmain) * 4 + (uint32_t)wave;
     if (tile >= sv.ntiles) return;
     __builtin_amdgcn_s_setprio(3);
     FwdLds& lds = lds_all[wave];
@@ -1144,7 +1262,9 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         acc[0] += (float)rows + ((const float*)lds.rec)[lane];
 #endif
     };
-    if ((h0 >> TILE_MODE_SHIFT) != TILE_MODE_RANGES) {                    // LIST or GROUPS: the group lists are there
+    if ((h0 >> TILE_MODE_SHIFT) == TILE_MODE_POINTS) {
+        return;                                   // scattered points: the helper workgroups do this tile (above)
+    } else if ((h0 >> TILE_MODE_SHIFT) != TILE_MODE_RANGES) {            // LIST or GROUPS: the group lists are there
         const uint32_t ng = hd[1 + g];                                    // this row's list length
         const uint32_t* gl = pv.glist + ((size_t)tile * 4 + g) * pv.list_cap;
         uint32_t nmax = hd[1] > hd[2] ? hd[1] : hd[2];
@@ -1475,6 +1595,7 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
             return gm;
         };
     };
+    if ((pv.hdr[(size_t)tile * TILE_HDR_WORDS] >> TILE_MODE_SHIFT) == TILE_MODE_POINTS) return;      // the helper workgroups' (backward_points_helper)
     for_each_step<BWD_STEP, WIDE>(pv, tile, lane, [&](uint32_t idx, uint32_t gm, bool have) {
         const float4 A = pv.rec[2 * idx], B = pv.rec[2 * idx + 1];
         wave_lds_fence();
@@ -1508,6 +1629,44 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
     }, ranges_mask);
 }
 
+// helper workgroups of the backward (plan.h, TILE_MODE_POINTS): four points at a time, 16 lanes per point, lane =
+// candidate.  No two lanes share a (point, Gaussian) pair, so there is nothing to reduce: NV atomics per pair
+// (such tiles are few, their points meet few Gaussians).
+template <int C, int MASK>
+__device__ __forceinline__ void backward_points_helper(const PlanView& pv, const SamplesView& sv, uint32_t hw, uint32_t nhw, int lane,
+                                                       const float* __restrict__ G0p, const float* __restrict__ G1p,
+                                                       const float* __restrict__ G2p, const float* __restrict__ G3p,
+                                                       const Resid<float>& rz) {
+    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;
+    constexpr int NV = BwdLayout<2, C>::N;
+    constexpr bool WIDE = (EM & (ORD2 | ORD3 | ORD2T)) != 0;
+    const uint32_t n = pv.params->n_points;
+    if (n == 0u) return;
+    const float q_cut = WIDE ? pv.params->q_b : pv.params->q_f;
+    const int row = lane >> 4, i = lane & 15;
+    for (uint32_t qd = hw; qd < n * 16u; qd += nhw) {
+        const uint32_t m = pv.ptiles[qd >> 4] * TILE_POINTS + (qd & 15u) * 4u + (uint32_t)row;
+        const bool valid = m < sv.M;
+        const SPoint sp = sv.spts[valid ? m : sv.M - 1];
+        const float s[2] = {sp.x, sp.y};
+        Gsym<float, 2, C, EM> G;
+        if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
+        else G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
+        if (!valid) continue;                      // a row without a point (whole rows: the 16 lanes share m)
+        walk_point<16>(pv, sp.x, sp.y, i, [&](uint32_t j, const float4 A, const float4 B) {
+            if (!(pair_q(A, B, sp.x, sp.y) > q_cut)) {
+                const Rec r = make_rec(A, B);
+                float part[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) part[q] = 0.f;
+                bwd_accumulate<float, 2, C, EM, (EM & ORD3) != 0, C == 1>(part, s, r.mu, r.con, r.v, G);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + j], part[q]);
+            }
+        });
+    }
+}
+
 template <int C, int MASK>
 __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_kernel(
     PlanView pv, SamplesView sv, const float* __restrict__ G0p, const float* __restrict__ G1p,
@@ -1515,7 +1674,13 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     __shared__ TileLdsBwd<BwdLayout<2, C>::N> lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = spread_tile(xcd_block() * 4 + (uint32_t)wave, sv.ntiles);
+    const uint32_t nmain = (sv.ntiles + 3u) / 4u;
+    if (blockIdx.x >= nmain) {
+        backward_points_helper<C, MASK>(pv, sv, (blockIdx.x - nmain) * 4u + (uint32_t)wave, (gridDim.x - nmain) * 4u, lane, G0p, G1p,
+                                        G2p, G3p, rz);
+        return;
+    }
+    const uint32_t tile = spread_tile(xcd_block(nmain) * 4 + (uint32_t)wave, sv.ntiles);
     if (tile >= sv.ntiles) return;
     backward_tile<C, MASK>(pv, sv, tile, lds_all[wave], lane, G0p, G1p, G2p, G3p, rz);
 }
@@ -1544,9 +1709,14 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void block_backward_ke
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nblocks = (sv.ntiles + 3u) / 4u;
+    if (blockIdx.x >= (nblocks + 3u) / 4u) {
+        backward_points_helper<C, MASK>(pv, sv, (blockIdx.x - (nblocks + 3u) / 4u) * 4u + (uint32_t)wave,
+                                        (gridDim.x - (nblocks + 3u) / 4u) * 4u, lane, G0p, G1p, G2p, G3p, rz);
+        return;
+    }
     // the same strips of the domain on the same XCD as the list build's; inside an XCD's chunk of 256 blocks the
     // blocks that run together are dealt apart (neighbours flush the same lines at the same moment: spread_tile)
-    uint32_t block = xcd_block_chunk<PIGS_XCD_CHUNK / 4>() * 4 + (uint32_t)wave;
+    uint32_t block = xcd_block_chunk<PIGS_XCD_CHUNK / 4>((nblocks + 3u) / 4u) * 4 + (uint32_t)wave;
     if (block >= nblocks) return;
     {
         const uint32_t base = block & ~255u;
@@ -1689,6 +1859,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     v.hdr = (const uint32_t*)(b + p.off_hdr);
     v.tlist = (const uint32_t*)(b + p.off_tlist);
     v.glist = (const uint32_t*)(b + p.off_glist);
+    v.ptiles = (const uint32_t*)(b + p.off_ptiles);
     v.N = (uint32_t)p.N;
     v.list_cap = p.list_cap;
     v.G0 = p.G0; v.L = p.L;
@@ -1799,6 +1970,8 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
         la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
         la.tlist = (uint32_t*)((char*)ws + p.off_tlist);
         la.glist = (uint32_t*)((char*)ws + p.off_glist);
+        la.ptiles = (uint32_t*)((char*)ws + p.off_ptiles);
+        la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
         hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)), dim3(256), 0, stream, la);
     }
     return launch_status();
@@ -1841,7 +2014,8 @@ int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags
 template <int C>
 static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, float* const* out, hipStream_t stream,
                           const Resid<float>& rz) {
-    const dim3 grid((sv.ntiles + 3) / 4), block(256);
+    // + the helper workgroups of the TILE_MODE_POINTS tiles (they leave at once when the plan queued none)
+    const dim3 grid((sv.ntiles + 3) / 4 + POINT_HELPER_BLOCKS), block(256);
     clear_hip_error();
 #define PIGS_CASE(MK)                                                                                          \
     case MK:                                                                                                   \
@@ -1859,10 +2033,10 @@ static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, f
 template <int C>
 static int plan_backward_c(const PlanView& pv, const SamplesView& sv, int mask, const float* const* g, float* gm,
                            float* gc, float* gv, hipStream_t stream, const Resid<float>& rz) {
-    const dim3 grid((sv.ntiles + 3) / 4), block(256);
+    const dim3 grid((sv.ntiles + 3) / 4 + POINT_HELPER_BLOCKS), block(256);
     clear_hip_error();
 #if PIGS_BWD_BLOCK
-    const dim3 bgrid((((sv.ntiles + 3) / 4) + 3) / 4);
+    const dim3 bgrid((((sv.ntiles + 3) / 4) + 3) / 4 + POINT_HELPER_BLOCKS);
 #define PIGS_CASE(MK)                                                                                             \
     case MK:                                                                                                      \
         hipLaunchKernelGGL((block_backward_kernel<C, MK>), bgrid, block, 0, stream, pv, sv, g[0], g[1], g[2], g[3], rz); \

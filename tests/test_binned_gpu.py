@@ -484,13 +484,14 @@ def test_plan_workspaces_are_recycled_only_after_their_plan_died(Sampler):
     assert kept[0].N == 300
 
 
-@pytest.mark.parametrize("N,mode", [(8000, "groups"), (20000, "ranges")])
+@pytest.mark.parametrize("N,mode", [(8000, "groups"), (20000, "points")])
 def test_sparse_scattered_points_keep_their_group_lists(Sampler, N, mode):
     """Points far apart from each other (the thin outskirts of a clustered cloud) share no Gaussians:
     a tile of 64 of them meets more than the tile list holds while its four group lists still fit.
     Such tiles keep their group lists (forward) and the backward walks those.  With more Gaussians per
-    point even a group list overflows: those tiles fall back to record ranges, whose records the
-    sampling kernels test against the group boxes themselves.  Results as ever in both cases."""
+    point even a group list overflows: those tiles keep no lists at all and every lane walks the Gaussian
+    grid around its own point at sampling time (TILE_MODE_POINTS; record ranges remain for tiles of close
+    points under very wide Gaussians: test_wide_gaussians_*).  Results as ever in both cases."""
     rng = np.random.default_rng(31)
     means, con, values = random_gaussians(rng, N, 1, log_sigma_mean=-4.6, log_sigma_std=0.2)
     core = rng.normal(0, 0.02, (60000, 2))                       # a dense core sets the cell size ...
@@ -499,7 +500,9 @@ def test_sparse_scattered_points_keep_their_group_lists(Sampler, N, mode):
     s = check_case(Sampler, means, con, values, samples, orders=(0, 1, 2), tol=TOL, gtol="bound")
     from tools.prof_step import list_stats
     st = list_stats(s._plan)
-    assert st["groups_only_tiles" if mode == "groups" else "ranges_tiles"] > 0, st      # the case is what it claims to be
+    # the case is what it claims to be: spread-out tiles with long or overflowing lists (the moderately sparse ones of
+    # the first case keep group lists only, or walk per point when that is cheaper; the second case's cannot keep lists)
+    assert (st["groups_only_tiles"] + st["points_tiles"] if mode == "groups" else st["points_tiles"]) > 0, st
 
 
 def test_backward_tile_shuffle_with_a_partial_last_chunk(Sampler):
@@ -559,3 +562,31 @@ def test_scan_recompute_path_gives_the_same_plan(Sampler):
         for name, g, w, b in zip(("means", "conics", "values"), (gm, gc, gv), want, bound):
             err = np.abs(g.cpu().double().numpy()[gsel] - w)
             assert (err <= b).all(), (flags, name, float((err / b).max()))
+
+
+def test_wide_gaussians_keep_record_ranges(Sampler):
+    """More Gaussians reach a 16-point group than a list holds (very wide Gaussians over close points): such
+    tiles keep the grid's record ranges around their box, and the sampling kernels test the ranges' records
+    against the group boxes themselves (the row-cooperative fallback; scattered points take the per-point
+    walk instead: test_sparse_scattered_points_keep_their_group_lists)."""
+    rng = np.random.default_rng(8)
+    means, con, values = random_gaussians(rng, 1500, 1, log_sigma_mean=-1.2, log_sigma_std=0.3, lo=-0.5, hi=0.5)
+    samples = rng.uniform(-0.5, 0.5, (3000, 2))
+    s = check_case(Sampler, means, con, values, samples, orders=(0, 1, 2), gtol="bound")
+    from tools.prof_step import list_stats
+    st = list_stats(s._plan)
+    assert st["ranges_tiles"] > 0 and st["points_tiles"] == 0, st
+
+
+def test_clustered_cloud_with_thin_outskirts(Sampler):
+    """Clamped normal points (test_no_mlp.py:86 draws randn / 2 clamped; here sigma = 0.15 of the half-width at
+    60 000 points): a dense core sets the sample cells' size, the outskirts are a few isolated points per
+    cell block.  Core tiles use lists, outskirt tiles the per-point walk; every point and every gradient
+    against the oracle."""
+    rng = np.random.default_rng(12)
+    means, con, values = random_gaussians(rng, 12000, 1, log_sigma_mean=-4.4, log_sigma_std=0.25)
+    samples = np.clip(rng.normal(0, 0.15, (60000, 2)), -1, 1)
+    s = check_case(Sampler, means, con, values, samples, orders=(0, 1, 2), gtol="bound")
+    from tools.prof_step import list_stats
+    st = list_stats(s._plan)
+    assert st["points_tiles"] > 0, st

@@ -29,11 +29,13 @@ def list_stats(plan):
     hdr = ws[off_hdr:off_hdr + 32 * ntiles].view(torch.int32).cpu().numpy().astype(np.uint32).reshape(ntiles, 8)
     mode, count = hdr[:, 0] >> 30, hdr[:, 0] & ((1 << 30) - 1)
     ng = hdr[:, 1:5].astype(np.float64)
-    lst = mode != 1            # 0: tile list + group lists, 2: group lists only, 1: record ranges
-    return {"tiles": int(ntiles), "list_cap": int(cap), "ranges_tiles": int((~lst).sum()), "groups_only_tiles": int((mode == 2).sum()),
-            "entries_mean": float(count[mode == 0].mean()), "entries_max": int(count[mode == 0].max()),
-            "rows_mean": float(ng[lst].max(1).mean()), "per_group_mean": float(ng[lst].mean()),
-            "per_group_max": int(ng[lst].max())}
+    lst = (mode == 0) | (mode == 2)     # 0: tile list + group lists, 2: group lists only, 1: record ranges, 3: every point walks the grid
+    return {"tiles": int(ntiles), "list_cap": int(cap), "ranges_tiles": int((mode == 1).sum()), "points_tiles": int((mode == 3).sum()),
+            "groups_only_tiles": int((mode == 2).sum()),
+            "entries_mean": float(count[mode == 0].mean()) if (mode == 0).any() else 0.0,
+            "entries_max": int(count[mode == 0].max()) if (mode == 0).any() else 0,
+            "rows_mean": float(ng[lst].max(1).mean()) if lst.any() else 0.0, "per_group_mean": float(ng[lst].mean()) if lst.any() else 0.0,
+            "per_group_max": int(ng[lst].max()) if lst.any() else 0}
 
 
 def main():
