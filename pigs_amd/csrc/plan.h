@@ -90,8 +90,8 @@ constexpr uint32_t TILE_MODE_LIST = 0u, TILE_MODE_RANGES = 1u, TILE_MODE_GROUPS 
 // in coarse levels whose 3 x 3 cells are most of the plan).
 constexpr float POINTS_MODE_MIN_CELLS = 16.f;
 constexpr uint32_t POINTS_MODE_MIN_LIST = 96u;
-constexpr uint32_t POINT_HELPER_BLOCKS = 64u;
-constexpr float POINTS_MODE_BLOCK_CELLS = 256.f;      // a 256-point block spread over more cells than this is not listed at all
+constexpr uint32_t POINT_HELPER_BLOCKS = 256u;
+constexpr float POINTS_MODE_BLOCK_CELLS = 64.f;       // a 256-point block spread over more cells than this is not listed at all
 constexpr int TILE_MODE_SHIFT = 30;
 constexpr uint32_t TILE_COUNT_MASK = (1u << TILE_MODE_SHIFT) - 1u;
 
