@@ -1018,12 +1018,18 @@ __device__ __forceinline__ void walk_point(const PlanView& pv, float x, float y,
         const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx < G - 1 ? cx + 1 : G - 1;
         const int cy0 = cy > 0 ? cy - 1 : 0, cy1 = cy < G - 1 ? cy + 1 : G - 1;
         const int csh = level_shift((uint32_t)(G * G));
-        for (int yy = cy0; yy <= cy1; ++yy) {
-            const uint32_t row = (uint32_t)(yy * G);
-            const uint32_t j0 = pv.starts[pv.level_off[l] + ((row + (uint32_t)cx0) << csh)];
-            const uint32_t j1 = pv.starts[pv.level_off[l] + ((row + (uint32_t)cx1 + 1u) << csh)];
-            for (uint32_t j = j0 + (uint32_t)i; j < j1; j += STRIDE) body(j, pv.rec[2 * (size_t)j], pv.rec[2 * (size_t)j + 1]);
+        // the (up to) three rows' record ranges first -- six independent loads, one round trip -- then the records
+        uint32_t j0[3], j1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = cy0 + r;
+            const uint32_t row = (uint32_t)((yy <= cy1 ? yy : cy1) * G);
+            j0[r] = pv.starts[pv.level_off[l] + ((row + (uint32_t)cx0) << csh)];
+            j1[r] = yy <= cy1 ? pv.starts[pv.level_off[l] + ((row + (uint32_t)cx1 + 1u) << csh)] : j0[r];
         }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            for (uint32_t j = j0[r] + (uint32_t)i; j < j1[r]; j += STRIDE) body(j, pv.rec[2 * (size_t)j], pv.rec[2 * (size_t)j + 1]);
     }
 }
 __device__ __forceinline__ float pair_q(const float4 A, const float4 B, float x, float y) {
