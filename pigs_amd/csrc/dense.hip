@@ -176,6 +176,136 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FEW POINTS (the reference's own training sizes: N ~ 1e3 Gaussians, 1 024 collocation points, main_pn.py:57,103;
+// model_pn.py:766-788): the kernels above give such a launch 16 workgroups on a 256-CU chip, each wave walking
+// its share of the Gaussians through a chain of scalar loads -- 16 us forward, 13-22 us backward where the
+// arithmetic is worth one.  These two spread the same sums over the whole chip.
+// ------------------------------------------------------------------------------------------
+
+// Forward: a workgroup of ROWS_WAVES waves takes 16 points; lane = 16 * row + i: point i of the workgroup, and
+// every (wave, row) pair one of 4 * ROWS_WAVES interleaved slices of the Gaussians (row-uniform loads: the 16
+// lanes of a row read the same record).  The four rows of a wave meet by two shuffles, the waves in LDS, in a
+// fixed order.  (8 waves: 256 VGPRs a wave -- the widest accumulator sets fit without spilling.)
+constexpr int ROWS_WAVES = 8;
+template <typename T, int D, int C, int MASK>
+__global__ __launch_bounds__(64 * ROWS_WAVES) void dense_forward_rows_kernel(
+    int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics, const T* __restrict__ values,
+    const T* __restrict__ samples, T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2, T* __restrict__ o3,
+    Resid<T> rz) {
+    using L = FwdLayout<D, C, MASK>;
+    constexpr int NF = Sym<D>::NF;
+    constexpr int SLICES = 4 * ROWS_WAVES;
+    __shared__ T red[ROWS_WAVES][L::N][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = lane >> 4, i = lane & 15;
+    const int64_t m = (int64_t)blockIdx.x * 16 + i;
+    const bool valid = m < M;
+    T s[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) s[k] = samples[(valid ? m : M - 1) * D + k];
+    T acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = T(0);
+    auto load = [&](int64_t n, T* mu, T* con, T* v) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) mu[k] = means[n * D + k];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) con[k] = conics[n * NF + k];
+#pragma unroll
+        for (int k = 0; k < C; ++k) v[k] = values[n * C + k];
+    };
+    // two Gaussians of the slice per iteration: their loads are in flight together
+    int64_t n = wave * 4 + row;
+    for (; n + SLICES < N; n += 2 * SLICES) {
+        T mu0[D], con0[NF], v0[C], mu1[D], con1[NF], v1[C];
+        load(n, mu0, con0, v0);
+        load(n + SLICES, mu1, con1, v1);
+        fwd_accumulate<T, D, C, MASK>(acc, s, mu0, con0, v0, &rz);
+        fwd_accumulate<T, D, C, MASK>(acc, s, mu1, con1, v1, &rz);
+    }
+    if (n < N) {
+        T mu0[D], con0[NF], v0[C];
+        load(n, mu0, con0, v0);
+        fwd_accumulate<T, D, C, MASK>(acc, s, mu0, con0, v0, &rz);
+    }
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) {
+        acc[k] += __shfl_xor(acc[k], 16);
+        acc[k] += __shfl_xor(acc[k], 32);
+    }
+    if (row == 0) {
+#pragma unroll
+        for (int k = 0; k < L::N; ++k) red[wave][k][i] = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0 && row == 0) {
+#pragma unroll
+        for (int k = 0; k < L::N; ++k) {
+            T t = red[0][k][i];
+            for (int w = 1; w < ROWS_WAVES; ++w) t += red[w][k][i];
+            acc[k] = t;
+        }
+        if (valid) fwd_store<T, D, C, MASK>(acc, m, o0, o1, o2, o3, &rz);
+    }
+}
+
+// Backward: lane = Gaussian (its parameters and 5 + c accumulators in VGPRs, as above); a workgroup = 4 waves =
+// 256 Gaussians against ONE slice of 64 points, which its threads fetch together into LDS (coordinates + the
+// symmetrised incoming gradients: what the scalar-load chain delivered two points at a time); every wave then
+// runs down the 64 points (wave-uniform LDS reads).  gridDim.y = slices of the points; partial sums meet by
+// atomics in buffers the caller zeroed.
+template <typename T, int D, int C, int MASK>
+__global__ __launch_bounds__(256) void dense_backward_staged_kernel(
+    int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics, const T* __restrict__ values,
+    const T* __restrict__ samples, const T* __restrict__ G0, const T* __restrict__ G1, const T* __restrict__ G2,
+    const T* __restrict__ G3, T* __restrict__ g_means, T* __restrict__ g_conics, T* __restrict__ g_values, Resid<T> rz) {
+    using L = BwdLayout<D, C>;
+    constexpr int NF = Sym<D>::NF;
+    constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;
+    struct Pt {
+        T s[D];
+        Gsym<T, D, C, EM> G;
+    };
+    __shared__ Pt pts[64];
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = n < N;
+    const int64_t nn = valid ? n : 0;
+    T mu[D], con[NF], v[C];
+#pragma unroll
+    for (int k = 0; k < D; ++k) mu[k] = means[nn * D + k];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) con[k] = conics[nn * NF + k];
+#pragma unroll
+    for (int k = 0; k < C; ++k) v[k] = values[nn * C + k];
+    const int64_t m0 = (int64_t)blockIdx.y * 64;
+    const int cnt = (int)(M - m0 < 64 ? M - m0 : 64);
+    if ((int)threadIdx.x < cnt) {
+        const int64_t m = m0 + threadIdx.x;
+        Pt p;
+#pragma unroll
+        for (int k = 0; k < D; ++k) p.s[k] = samples[m * D + k];
+        if constexpr (MASK == ORDR) p.G.load_residual(m, G0, rz);
+        else p.G.load(m, G0, G1, G2, G3);
+        pts[threadIdx.x] = p;
+    }
+    __syncthreads();
+    T acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = T(0);
+    for (int t = 0; t < cnt; ++t) bwd_accumulate<T, D, C, EM, true>(acc, pts[t].s, mu, con, v, pts[t].G);
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) atomicAdd(&g_means[n * D + k], acc[L::MU + k]);
+#pragma unroll
+        for (int k = 0; k < NF; ++k) atomicAdd(&g_conics[n * NF + k], acc[L::CON + k]);
+#pragma unroll
+        for (int k = 0; k < C; ++k) atomicAdd(&g_values[n * C + k], acc[L::VAL + k]);
+    }
+}
+
 // zero three word arrays (the atomically accumulated gradient buffers) in one launch
 __global__ __launch_bounds__(256) void zero_grads_kernel(uint32_t* __restrict__ p0, uint64_t n0, uint32_t* __restrict__ p1,
                                                          uint64_t n1, uint32_t* __restrict__ p2, uint64_t n2) {
@@ -203,7 +333,18 @@ static int launch_dense_forward(const SampleArgs& a, hipStream_t stream) {
     const Resid<T> rz{(T)a.resid[0], {(T)a.resid[1], (T)a.resid[2]}, (T)a.resid[3], (const T*)a.target};
     constexpr int NACC = FwdLayout<D, C, MASK>::N;
     // few point blocks: spread the Gaussian loop over 16 waves per workgroup
-    constexpr bool can16 = (15 * NACC * 64 * sizeof(T) <= 60 * 1024);
+    // (a 1 024-thread workgroup leaves 128 VGPRs per wave: the wide accumulator sets -- several channels, third
+    // derivatives, float64 -- spilled there, so they keep the four-wave variant)
+    constexpr bool can16 = (15 * NACC * 64 * sizeof(T) <= 60 * 1024) && NACC * (sizeof(T) / 4) <= 7;
+    // few points (<= 256 of the 64-point blocks above): 16 points per workgroup, the Gaussians in 32 slices
+    constexpr bool can_rows = NACC * (sizeof(T) / 4) <= 28;      // beyond, the two records in flight spill even at 256 VGPRs
+    if constexpr (can_rows) {
+        if (blocks <= 256 && a.N >= 128) {
+            hipLaunchKernelGGL((dense_forward_rows_kernel<T, D, C, MASK>), dim3((unsigned)((a.M + 15) / 16)), dim3(64 * ROWS_WAVES), 0, stream,
+                               a.N, a.M, means, conics, values, samples, o0, o1, o2, o3, rz);
+            return launch_status();
+        }
+    }
     if constexpr (can16) {
       if (blocks < 1024 && a.N >= 64) {
         hipLaunchKernelGGL((dense_forward_kernel<T, D, C, MASK, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream,
@@ -238,6 +379,15 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     };
     if (a.M == 0) {
         zero_grads();
+        return launch_status();
+    }
+    // few points: 64-point slices staged in LDS, 256 Gaussians per workgroup (dense_backward_staged_kernel)
+    if (a.M <= 16384 && (a.M + 63) / 64 <= 65535) {
+        zero_grads();
+        hipLaunchKernelGGL((dense_backward_staged_kernel<T, D, C, MASK>), dim3((unsigned)((a.N + 255) / 256), (unsigned)((a.M + 63) / 64)),
+                           dim3(256), 0, stream, a.N, a.M, (const T*)a.means, (const T*)a.conics, (const T*)a.values,
+                           (const T*)a.samples, (const T*)a.gout[0], (const T*)a.gout[1], (const T*)a.gout[2], (const T*)a.gout[3],
+                           gm, gc, gv, Resid<T>{(T)a.resid[0], {(T)a.resid[1], (T)a.resid[2]}, (T)a.resid[3], nullptr});
         return launch_status();
     }
     // split the point range over gridDim.y so that ~2048 workgroups exist; each wave should
