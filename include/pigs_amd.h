@@ -119,8 +119,22 @@ int pigs_build_covariances_backward(int dtype, int64_t N, const void* scaling, c
 size_t pigs_samples_workspace_bytes(int64_t M);                  /* 0 = unsupported size */
 size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsupported sizes */
 
-/* samples workspace alone (4 launches) */
+/* samples workspace alone (4 launches; 5 on the coarse-bin path).
+ * Two ways to sort the points, same result (the order inside a 16-point cell aside): ONE PASS -- one returning
+ * atomic per run of consecutive points that share a cell, right for lattices in row order -- and COARSE BINS --
+ * per-workgroup LDS ranking inside 256 coarse bins, a scan of the (bin, workgroup) counts, a scatter into bin
+ * segments and a per-bin LDS sort; right for points in no order (torch.rand collocation points, main_pn.py:103),
+ * which otherwise pay one global atomic and one 12-byte scattered write each.  The host cannot see which it
+ * has without a synchronisation, so the library remembers, per device and M: every build of M >= 32 768
+ * points leaves {runs, points} of a sample of its waves in the workspace, copied to pinned memory on `stream`
+ * behind the build (nobody waits); the next build of the same M takes the path the last completed copy
+ * recommends (more than 0.55 runs per point: coarse bins).  Captured builds neither ask nor copy.
+ * PIGS_SAMPLES_ORDER=ordered|unordered in the environment overrules the memory (tests), as do the
+ * PIGS_BUILD_POINTS_* flags of pigs_plan_build. */
 int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream);
+/* what the library currently remembers for builds of M points on the current device: 1 = coarse bins,
+ * 0 = one pass, -1 = nothing yet (introspection for tools and tests) */
+int pigs_samples_order_hint(int64_t M);
 
 /* plan workspace.  `flags`:
  *   PIGS_BUILD_SAMPLES       also (re)builds the samples workspace from `samples` in the same launches
@@ -135,10 +149,15 @@ int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, con
  * (ABI 4 called this parameter build_samples: 0 / 1 keep their meaning.)
  *   PIGS_BUILD_DEBUG_NO_LOOKBACK  test hook: the in-kernel scans never use their workgroup-to-workgroup
  *                            hand-over and take the recompute path everywhere (see pigs_*_error_offset);
- *                            results are the same, the build is slower. */
+ *                            results are the same, the build is slower.
+ *   PIGS_BUILD_POINTS_ORDERED / PIGS_BUILD_POINTS_UNORDERED  (with PIGS_BUILD_SAMPLES) the caller knows how its
+ *                            points arrive: take the one-pass / the coarse-bin samples build whatever the
+ *                            library remembers (see pigs_samples_build); neither flag: the library decides. */
 #define PIGS_BUILD_SAMPLES 1
 #define PIGS_BUILD_PLAN_WS_CLEAN 2
 #define PIGS_BUILD_DEBUG_NO_LOOKBACK 4
+#define PIGS_BUILD_POINTS_ORDERED 8
+#define PIGS_BUILD_POINTS_UNORDERED 16
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
                     int flags, int64_t N, int64_t M, int c, float q_max, float q_max_backward,
                     const void* means, const void* conics, const void* values, const void* samples, void* stream);

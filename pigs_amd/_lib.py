@@ -36,6 +36,7 @@ SIGNATURES = {
     "pigs_samples_error_offset": (ctypes.c_size_t, []),
     "pigs_plan_error_offset": (ctypes.c_size_t, []),
     "pigs_samples_build": (_i, [_vp, ctypes.c_size_t, _i64, _vp, _vp]),
+    "pigs_samples_order_hint": (_i, [_i64]),
     "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _i64, _i64, _i, ctypes.c_float, ctypes.c_float]
                         + [_vp] * 4 + [_vp]),
     "pigs_plan_forward": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i64, _i64, _i, ctypes.c_float, _i]

@@ -99,6 +99,8 @@ int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, con
     return samples_build(samples_ws, samples_ws_bytes, M, samples, (hipStream_t)stream);
 }
 
+int pigs_samples_order_hint(int64_t M) { return samples_order_hint(M); }
+
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
                     int flags, int64_t N, int64_t M, int c, float q_max, float q_max_backward, const void* means,
                     const void* conics, const void* values, const void* samples, void* stream) {

@@ -49,6 +49,7 @@ int aggregate_backward(const AggregateArgs& a, hipStream_t stream);
 size_t samples_workspace_bytes(int64_t M);
 size_t plan_workspace_bytes(int64_t N, int64_t M, int c);
 int samples_build(void* sws, size_t sws_bytes, int64_t M, const void* samples, hipStream_t stream);
+int samples_order_hint(int64_t M);
 int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags, int64_t N, int64_t M, int c,
                float q_max, float q_max_backward, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream);

@@ -113,6 +113,12 @@ struct SampleParams {
     float box[4];          // min x, min y, max x, max y of the finite sample coordinates (+-inf when none)
     SampleGrid sg;
     uint32_t scan_error;   // set when the scan's bounded spin ran out (never in a healthy run)
+    // how ordered the caller's points are: over a sample of the build's waves, {runs of consecutive points
+    // that share a fine cell, points}.  A lattice in row order has runs of ~4 (0.25 runs per point); shuffled
+    // or random points have one run per point -- every point then pays its own returning atomic in the
+    // one-pass build, and the next build of a point set of this size takes the coarse-bin path
+    // (SAMPLES_COARSE_BINS below; the library reads this pair back without synchronising, plan.hip).
+    uint32_t order_stat[2];
 };
 
 // Written once per plan build (first bytes of the plan workspace), read by the sampling kernels.
@@ -130,12 +136,35 @@ struct PlanParams {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- samples workspace ------------------------------------------------------------------------
+// Two ways to sort the points into fine-cell order.  ONE PASS (points that arrive in runs sharing a cell: any
+// lattice in row order): cell key + rank by one returning atomic per run, scan of the fine-cell counters,
+// scatter.  COARSE BINS (points in no order: one global returning atomic per point, ~1 M of them at 20 per ns,
+// and 12-byte scattered writes over the whole array): the fine cells are grouped into SAMPLES_COARSE_BINS
+// contiguous id ranges (the cell path is spatially coherent, so a bin is a compact patch); a workgroup ranks
+// its chunk of points inside each bin with LDS atomics and publishes one count per (bin, workgroup); the scan
+// runs over that matrix; the scatter moves every point to its bin's segment of a temporary array (16-byte
+// records, runs of a workgroup's points of one bin are contiguous); one workgroup per bin then counting-sorts
+// its segment by fine cell in LDS into the final array -- writes that stay inside a ~50 KB window.  One more
+// launch, two more passes over the points, no global atomics.
+constexpr uint32_t SAMPLES_COARSE_BINS = 256;      // = threads of a build workgroup (one bin per thread where bins are walked)
+constexpr uint32_t SAMPLES_MAX_HIST_WGS = 1024;    // workgroups (chunks of the point array) of the coarse histogram
+constexpr uint32_t SAMPLES_MAX_CELLS_PER_BIN = 12288;      // LDS counters of the per-bin sort (48 KB)
+struct STmp {                  // a point on its way through the coarse-bin path
+    float x, y;
+    uint32_t m, id;            // index in the caller's array, fine cell id
+};
 struct SamplesLayout {
     int64_t M;
     uint32_t scells_cap;       // capacity (upper bound) of fine sample cells, multiple of 16
     uint32_t scan_blocks;      // workgroups of the scan = ceil((scells_cap + 1) / PLAN_SCAN_BLOCK)
     uint32_t ntiles;           // ceil(M / 64)
-    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_skey, off_spts, total_bytes;
+    // coarse-bin path
+    uint32_t cells_per_bin;    // fine cell ids per coarse bin: bin = id / cells_per_bin < SAMPLES_COARSE_BINS
+    uint32_t h_chunk;          // points per histogram workgroup (a multiple of 1024)
+    uint32_t h_wgs;            // histogram workgroups (a multiple of 4: the matrix is whole scan blocks)
+    uint32_t h_scan_blocks;    // = SAMPLES_COARSE_BINS * h_wgs / PLAN_SCAN_BLOCK
+    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_skey, off_spts, off_hist, off_hagg, off_hstarts,
+        off_tmp, total_bytes;
 };
 
 inline SamplesLayout make_samples_layout(int64_t M) {
@@ -157,6 +186,16 @@ inline SamplesLayout make_samples_layout(int64_t M) {
     p.off_starts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
     p.off_skey = o;     o = align_up(o + sizeof(uint2) * (size_t)M, 256);      // {cell id, rank in cell}
     p.off_spts = o;     o = align_up(o + sizeof(SPoint) * (size_t)M, 256);
+    // coarse-bin path: the (bin, workgroup) count matrix, its scan, the temporary array
+    p.cells_per_bin = (p.scells_cap + SAMPLES_COARSE_BINS - 1) / SAMPLES_COARSE_BINS;
+    const int64_t chunks = (M + 1023) / 1024;
+    p.h_chunk = (uint32_t)((chunks + SAMPLES_MAX_HIST_WGS - 1) / SAMPLES_MAX_HIST_WGS) * 1024u;
+    p.h_wgs = (uint32_t)(((M + p.h_chunk - 1) / p.h_chunk + 3) / 4 * 4);
+    p.h_scan_blocks = SAMPLES_COARSE_BINS * p.h_wgs / PLAN_SCAN_BLOCK;
+    p.off_hist = o;     o = align_up(o + sizeof(uint32_t) * (size_t)p.h_scan_blocks * PLAN_SCAN_BLOCK, 256);
+    p.off_hagg = o;     o = align_up(o + sizeof(uint64_t) * (size_t)p.h_scan_blocks, 256);
+    p.off_hstarts = o;  o = align_up(o + sizeof(uint32_t) * (size_t)p.h_scan_blocks * PLAN_SCAN_BLOCK, 256);
+    p.off_tmp = o;      o = align_up(o + sizeof(STmp) * (size_t)M, 256);
     p.total_bytes = o;
     return p;
 }

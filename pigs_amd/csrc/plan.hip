@@ -22,9 +22,15 @@
 #include "plan.h"
 #include "grid_walk.h"
 #include "launch.h"
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 #ifndef PIGS_FWD_WAVES
 #define PIGS_FWD_WAVES 8      // waves per SIMD the forward kernel's register budget is held to
+#endif
+#ifndef PIGS_FWD_WG_WAVES
+#define PIGS_FWD_WG_WAVES 4   // waves (= tiles) per workgroup of the forward kernel
 #endif
 #ifndef PIGS_FWD_UNROLL
 #define PIGS_FWD_UNROLL 2     // list rows evaluated per loop iteration
@@ -65,6 +71,12 @@ struct BuildArgs {
     SPoint* spts;
     const float* samples;
     uint32_t M, scells_cap, s_scan_blocks, s_zero_words;
+    uint32_t* szero;      // what the bbox launch zeroes for the samples side (s_zero_words): counters + scan aggregates
+    // coarse-bin path of the samples build (plan.h): scounts / sagg / sstarts then are the (bin, workgroup) count
+    // matrix, its scan aggregates and its scan
+    int coarse;
+    uint32_t cells_per_bin, h_chunk, h_wgs;
+    STmp* tmp;
     // plan side
     PlanParams* params;
     uint32_t* counts;     // [scan_blocks * PLAN_SCAN_BLOCK] Gaussian cell counters, followed by the scan aggregates
@@ -99,7 +111,8 @@ __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
 // loads (16 points) in flight per thread, written as a plain partial.
 __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     __shared__ float sh[4][4];
-    zero_words(a.scounts, a.s_zero_words);
+    zero_words(a.szero, a.s_zero_words);
+    if (blockIdx.x == 0 && threadIdx.x < 2) a.sparams->order_stat[threadIdx.x] = 0u;
     if (a.do_plan) {
         zero_words(a.counts, a.zero_words);
         if (blockIdx.x == 0 && threadIdx.x < PLAN_BAR_WORDS) a.params->bar[threadIdx.x] = 0u;
@@ -185,8 +198,14 @@ __device__ __forceinline__ Run run_of(uint32_t k, int lane) {
     return r;
 }
 
+// The coarse-bin path's first pass (plan.h): workgroup w ranks its chunk of the point array inside every coarse
+// bin with LDS atomics (one per point; random points spread over the 256 counters) and publishes its 256 counts
+// as column w of the (bin, workgroup) matrix; a point keeps {fine cell, rank in (bin, workgroup)}.
+__device__ __forceinline__ void samples_hist_part(const BuildArgs& a, uint32_t w, const SampleGrid& sg, uint32_t* lh, int lane);
+
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     __shared__ float shb[4][4];
+    __shared__ uint32_t lh[SAMPLES_COARSE_BINS];
     const int lane = threadIdx.x & 63;
     // Every dependent memory round trip costs 2-4 us in this kernel (in-kernel stamps): issue the
     // workgroup's own loads first, so they fly while the bounding-box partials are reduced.
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             gm[0] = a.means[2 * gi]; gm[1] = a.means[2 * gi + 1];
             gc[0] = a.conics[3 * gi]; gc[1] = a.conics[3 * gi + 1]; gc[2] = a.conics[3 * gi + 2];
         }
-    } else {
+    } else if (!a.coarse) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t i = i0 + 64 * k;
@@ -260,6 +279,8 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
         base = __shfl(base, r.start);
         if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
+    } else if (a.coarse) {
+        samples_hist_part(a, blockIdx.x - gblocks, sg, lh, lane);
     } else {
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
         uint32_t id[4], base[4];
@@ -288,7 +309,43 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             const uint32_t b = __shfl(base[k], r[k].start);
             if (i < a.M) a.skey[i] = make_uint2(id[k], b + (uint32_t)(lane - r[k].start));
         }
+        if (((blockIdx.x - gblocks) & 31u) == 0u) {      // a sample of the waves: runs per point (SampleParams::order_stat)
+            uint32_t runs = 0, pts = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                runs += (uint32_t)__builtin_popcountll(__ballot(r[k].leader && id[k] != 0xffffffffu));
+                pts += (uint32_t)__builtin_popcountll(__ballot(id[k] != 0xffffffffu));
+            }
+            if (lane == 0) { atomicAdd(&a.sparams->order_stat[0], runs); atomicAdd(&a.sparams->order_stat[1], pts); }
+        }
     }
+}
+
+__device__ __forceinline__ void samples_hist_part(const BuildArgs& a, uint32_t w, const SampleGrid& sg, uint32_t* lh, int lane) {
+    static_assert(SAMPLES_COARSE_BINS == 256, "one bin per thread of the workgroup");
+    lh[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)w * a.h_chunk;
+    const uint64_t p1 = p0 + a.h_chunk < (uint64_t)a.M ? p0 + a.h_chunk : (uint64_t)a.M;
+    // the same statistic as the one-pass build keeps, from the chunk's first 256 points (all lanes present)
+    const bool sampled = (w & 31u) == 0u && p0 + 256u <= p1;
+    bool first = true;
+    for (uint64_t i = p0 + threadIdx.x; i < p1; i += 256u) {
+        const float2 p = ((const float2*)a.samples)[i];
+        const int cx = (int)clampf((p.x - sg.ox) * sg.inv_w, 0.f, (float)(sg.nx - 1));
+        const int cy = (int)clampf((p.y - sg.oy) * sg.inv_w, 0.f, (float)(sg.ny - 1));
+        const uint32_t id = sample_cell_id(cx, cy, sg.nx);
+        const uint32_t rank = atomicAdd(&lh[id / a.cells_per_bin], 1u);
+        a.skey[i] = make_uint2(id, rank);
+        if (sampled && first) {
+            const Run r = run_of(id, lane);
+            const uint32_t runs = (uint32_t)__builtin_popcountll(__ballot(r.leader));
+            if (lane == 0) { atomicAdd(&a.sparams->order_stat[0], runs); atomicAdd(&a.sparams->order_stat[1], 64u); }
+        }
+        first = false;
+    }
+    __syncthreads();
+    a.scounts[(size_t)threadIdx.x * a.h_wgs + w] = lh[threadIdx.x];
 }
 
 // Launch 3: exclusive scan counts -> starts in ONE launch, for the Gaussian cells and (when the
@@ -437,9 +494,87 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     if (!gpart && i < a.M) {
         const uint2 kr = a.skey[i];
         const float2 p = ((const float2*)a.samples)[i];
+        if (a.coarse) {
+            // coarse-bin path: to the point's bin segment of the temporary array, behind the points that earlier
+            // workgroups (chunks) sent to this bin; the fine cell travels along
+            const uint32_t w = i / a.h_chunk, bin = kr.x / a.cells_per_bin;
+            STmp t;
+            t.x = p.x; t.y = p.y; t.m = i; t.id = kr.x;
+            a.tmp[a.sstarts[(size_t)bin * a.h_wgs + w] + kr.y] = t;
+        } else {
+            SPoint sp;
+            sp.x = p.x; sp.y = p.y; sp.m = i;
+            a.spts[a.sstarts[kr.x] + kr.y] = sp;
+        }
+    }
+}
+
+// Last launch of the coarse-bin path: one workgroup per coarse bin counting-sorts the bin's segment of the
+// temporary array by fine cell into the final array.  LDS: one counter per fine cell of the bin (count, then
+// -- scanned in place -- cursor).  Both passes read the segment (~4 096 points at 1 M, L2 resident); the writes
+// stay inside the segment.  Order inside a cell: as the atomics fall (as in the one-pass build).
+__global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
+    extern __shared__ uint32_t cnt[];       // [cells_per_bin]
+    __shared__ uint32_t wsum[16];
+    constexpr int B = 8;                    // points a thread keeps in registers: segments up to 8 192 points are read once
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t seg0 = a.sstarts[(size_t)b * a.h_wgs];
+    const uint32_t seg1 = b + 1 < SAMPLES_COARSE_BINS ? a.sstarts[(size_t)(b + 1) * a.h_wgs] : a.M;
+    const uint32_t id0 = b * a.cells_per_bin, ncell = a.cells_per_bin;
+    const bool one_batch = seg1 - seg0 <= (uint32_t)B * 1024u;      // block-uniform
+    const uint4* tmp4 = (const uint4*)a.tmp;
+    uint4 r[B];
+    if (one_batch) {                         // the loads fly while the counters are cleared
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const uint32_t p = seg0 + (uint32_t)k * 1024u + tid;
+            r[k] = p < seg1 ? tmp4[p] : make_uint4(0u, 0u, 0u, 0xffffffffu);
+        }
+    }
+    for (uint32_t t = tid; t < ncell; t += 1024u) cnt[t] = 0u;
+    __syncthreads();
+    if (one_batch) {
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (r[k].w != 0xffffffffu) atomicAdd(&cnt[r[k].w - id0], 1u);
+    } else {
+        for (uint32_t p = seg0 + tid; p < seg1; p += 1024u) atomicAdd(&cnt[a.tmp[p].id - id0], 1u);
+    }
+    __syncthreads();
+    // exclusive scan in place: thread t owns the `per` consecutive counters from t * per
+    const uint32_t per = (ncell + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = lo + per < ncell ? lo + per : ncell;
+    uint32_t sum = 0;
+    for (uint32_t t = lo; t < hi; ++t) sum += cnt[t];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w2 = 0; w2 < wave; ++w2) run += wsum[w2];
+    for (uint32_t t = lo; t < hi; ++t) {
+        const uint32_t c = cnt[t];
+        cnt[t] = run;
+        run += c;
+    }
+    __syncthreads();
+    auto place = [&](const uint4 t) {
+        const uint32_t k = atomicAdd(&cnt[t.w - id0], 1u);
         SPoint sp;
-        sp.x = p.x; sp.y = p.y; sp.m = i;
-        a.spts[a.sstarts[kr.x] + kr.y] = sp;
+        sp.x = __uint_as_float(t.x); sp.y = __uint_as_float(t.y); sp.m = t.z;
+        a.spts[seg0 + k] = sp;
+    };
+    if (one_batch) {
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+            if (r[k].w != 0xffffffffu) place(r[k]);
+    } else {
+        for (uint32_t p = seg0 + tid; p < seg1; p += 1024u) place(tmp4[p]);
     }
 }
 
@@ -1183,22 +1318,23 @@ constexpr int fwd_waves() {
     return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1 || MASK == ORDR)) ? PIGS_FWD_WAVES : 6;
 }
 template <int C, int MASK>
-__global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kernel(
+__global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) void tile_forward_kernel(
     PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
     float* __restrict__ o3, Resid<float> rz) {
     using L = FwdLayout<2, C, MASK>;
     constexpr int U = PIGS_FWD_UNROLL;
-    __shared__ FwdLds lds_all[4];
+    constexpr uint32_t FW = PIGS_FWD_WG_WAVES;
+    __shared__ FwdLds lds_all[FW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nmain = (sv.ntiles + 3u) / 4u;
+    const uint32_t nmain = (sv.ntiles + FW - 1u) / FW;
     if (blockIdx.x >= nmain) {
         // helper workgroups (plan.h, TILE_MODE_POINTS): four points at a time, 16 lanes per point, lane = candidate
         const uint32_t n = pv.params->n_points;
         if (n == 0u) return;
         const float q_f = pv.params->q_f;
         const int row = lane >> 4, i = lane & 15;
-        const uint32_t hw = (blockIdx.x - nmain) * 4u + (uint32_t)wave, nhw = (gridDim.x - nmain) * 4u;
+        const uint32_t hw = (blockIdx.x - nmain) * FW + (uint32_t)wave, nhw = (gridDim.x - nmain) * FW;
         for (uint32_t qd = hw; qd < n * 16u; qd += nhw) {
             const uint32_t m = pv.ptiles[qd >> 4] * TILE_POINTS + (qd & 15u) * 4u + (uint32_t)row;
             const bool valid = m < sv.M;
@@ -1223,7 +1359,7 @@ __global__ __launch_bounds__(256, (fwd_waves<C, MASK>())) void tile_forward_kern
         }
         return;
     }
-    const uint32_t tile = xcd_block(nmain) * 4 + (uint32_t)wave;
+    const uint32_t tile = xcd_block_chunk<PIGS_XCD_CHUNK * 4 / FW>(nmain) * FW + (uint32_t)wave;
     if (tile >= sv.ntiles) return;
     __builtin_amdgcn_s_setprio(3);
     FwdLds& lds = lds_all[wave];
@@ -1902,20 +2038,141 @@ size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
     return make_plan_layout(N, M, c).total_bytes;
 }
 
-static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, const void* samples) {
+static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, const void* samples, bool coarse) {
     char* b = (char*)sws;
     a.sparams = (SampleParams*)(b + s.off_params);
     a.sboxes = (float4*)(b + s.off_boxes);
-    a.scounts = (uint32_t*)(b + s.off_counts);
-    a.sagg = (unsigned long long*)(b + s.off_agg);
-    a.sstarts = (uint32_t*)(b + s.off_starts);
     a.skey = (uint2*)(b + s.off_skey);
     a.spts = (SPoint*)(b + s.off_spts);
     a.samples = (const float*)samples;
     a.M = (uint32_t)s.M;
     a.scells_cap = s.scells_cap;
-    a.s_scan_blocks = s.scan_blocks;
-    a.s_zero_words = (uint32_t)((s.off_starts - s.off_counts) / 4);     // counters + aggregates
+    a.coarse = coarse;
+    a.cells_per_bin = s.cells_per_bin; a.h_chunk = s.h_chunk; a.h_wgs = s.h_wgs;
+    a.tmp = (STmp*)(b + s.off_tmp);
+    if (coarse) {      // the scan runs over the (bin, workgroup) count matrix, which every build overwrites whole
+        a.scounts = (uint32_t*)(b + s.off_hist);
+        a.sagg = (unsigned long long*)(b + s.off_hagg);
+        a.sstarts = (uint32_t*)(b + s.off_hstarts);
+        a.s_scan_blocks = s.h_scan_blocks;
+        a.szero = (uint32_t*)(b + s.off_hagg);
+        a.s_zero_words = (uint32_t)((s.off_hstarts - s.off_hagg) / 4);    // the scan's aggregates
+    } else {
+        a.scounts = (uint32_t*)(b + s.off_counts);
+        a.sagg = (unsigned long long*)(b + s.off_agg);
+        a.sstarts = (uint32_t*)(b + s.off_starts);
+        a.s_scan_blocks = s.scan_blocks;
+        a.szero = a.scounts;
+        a.s_zero_words = (uint32_t)((s.off_starts - s.off_counts) / 4);     // counters + aggregates
+    }
+}
+
+// ---- which way a samples build sorts its points (plan.h, SamplesLayout) ----
+// Unordered points want the coarse-bin path, points in runs the one-pass build, and the host cannot look at
+// the points without a synchronisation.  So every build of a large point set leaves {runs, points} of a sample
+// of its waves in the workspace header, the library copies that pair to pinned memory on the build's stream
+// behind the build (no wait), and the NEXT build of a point set of the same size on the same device takes what
+// the last completed copy says: a training loop that draws new random collocation points every step
+// (main_pn.py:103, test_no_mlp.py:86) switches after its first step or two, a lattice never does.  A capture
+// neither asks nor copies (it keeps the mode of the moment).  PIGS_SAMPLES_ORDER = ordered | unordered in the
+// environment, or the PIGS_BUILD_POINTS_* flags, overrule the memory; the result is the same either way
+// (order inside a fine cell aside), only the time differs.
+constexpr int64_t COARSE_MIN_POINTS = 1 << 15;      // below: the build is a handful of launch latencies either way
+struct OrderHint {
+    int device = -1;
+    int64_t M = 0;
+    bool coarse = false, pending = false;
+    uint32_t builds = 0;           // samples builds of this (device, M) so far: the statistic is asked for after the first
+                                   // two and after every 16th (the 8-byte copy is a 4 us blit in the build's stream)
+    hipEvent_t ev = nullptr;
+    uint32_t* host = nullptr;      // pinned {runs, points}
+    uint64_t stamp = 0;
+};
+static std::mutex g_hint_mu;
+static OrderHint g_hints[8];
+static uint64_t g_hint_clock = 0;
+
+static OrderHint* hint_entry(int device, int64_t M, bool create) {      // g_hint_mu held
+    OrderHint* lru = nullptr;
+    for (auto& h : g_hints) {
+        if (h.device == device && h.M == M) { h.stamp = ++g_hint_clock; return &h; }
+        if (!h.pending && (!lru || h.stamp < lru->stamp)) lru = &h;
+    }
+    if (!create || !lru) return nullptr;
+    if (lru->ev && lru->device != device) {      // an event belongs to the device it was created on
+        (void)hipEventDestroy(lru->ev);
+        lru->ev = nullptr;
+    }
+    if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (!lru->host && hipHostMalloc((void**)&lru->host, 2 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
+    lru->device = device; lru->M = M; lru->coarse = false; lru->pending = false; lru->builds = 0; lru->stamp = ++g_hint_clock;
+    return lru;
+}
+
+static bool stream_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+// order: 0 = ask the memory, 1 = one pass, 2 = coarse bins
+static bool samples_take_coarse(const SamplesLayout& s, int order, hipStream_t stream) {
+    if (s.cells_per_bin > SAMPLES_MAX_CELLS_PER_BIN) return false;
+    if (const char* e = getenv("PIGS_SAMPLES_ORDER")) {
+        if (!strcmp(e, "ordered")) order = 1;
+        else if (!strcmp(e, "unordered")) order = 2;
+    }
+    if (order) return order == 2;
+    if (s.M < COARSE_MIN_POINTS) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    OrderHint* h = hint_entry(dev, s.M, false);
+    if (!h) return false;
+    if (h->pending && !stream_capturing(stream)) {
+        const hipError_t q = hipEventQuery(h->ev);
+        (void)hipGetLastError();          // hipErrorNotReady is an answer, not a failure
+        if (q == hipSuccess) {
+            h->pending = false;
+            if (h->host[1] > 0u) h->coarse = (uint64_t)h->host[0] * 100u > (uint64_t)h->host[1] * 55u;
+        }
+    }
+    return h->coarse;
+}
+
+// behind a samples build: ask for its {runs, points}
+static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t stream) {
+    if (s.M < COARSE_MIN_POINTS || s.cells_per_bin > SAMPLES_MAX_CELLS_PER_BIN || getenv("PIGS_SAMPLES_ORDER")) return;
+    if (stream_capturing(stream)) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    OrderHint* h = hint_entry(dev, s.M, true);
+    if (!h) return;
+    const uint32_t nth = h->builds++;
+    if (h->pending || (nth >= 2u && (nth & 15u) != 0u)) return;
+    const SampleParams* sp = (const SampleParams*)((const char*)sws + s.off_params);
+    if (hipMemcpyAsync(h->host, sp->order_stat, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(h->ev, stream) == hipSuccess)
+        h->pending = true;
+    (void)hipGetLastError();
+}
+
+int samples_order_hint(int64_t M) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    OrderHint* h = hint_entry(dev, M, false);
+    if (!h) return -1;
+    if (h->pending) {
+        const hipError_t q = hipEventQuery(h->ev);
+        (void)hipGetLastError();
+        if (q == hipSuccess) {
+            h->pending = false;
+            if (h->host[1] > 0u) h->coarse = (uint64_t)h->host[0] * 100u > (uint64_t)h->host[1] * 55u;
+        }
+    }
+    return h->coarse ? 1 : 0;
 }
 
 static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_f, float q_b, const void* means,
@@ -1943,13 +2200,14 @@ static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_
 // (build_plan) or both in the same four launches, then the tile lists.
 static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_lookback, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
                      int64_t M, int c, float q_max, float q_max_b, const void* means, const void* conics, const void* values,
-                     const void* samples, hipStream_t stream, bool build_lists = true) {
+                     const void* samples, hipStream_t stream, bool build_lists = true, int order = 0) {
     if (!samples_supported(M)) return PIGS_ERR_UNSUPPORTED;
     const SamplesLayout s = make_samples_layout(M);
     if (!sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
     BuildArgs a{};
     a.do_samples = do_samples; a.do_plan = do_plan; a.no_lookback = no_lookback;
-    fill_samples_args(a, s, sws, samples);
+    const bool coarse = do_samples && samples_take_coarse(s, order, stream);
+    fill_samples_args(a, s, sws, samples, coarse);
     PlanLayout p{};
     if (do_plan) {
         if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
@@ -1967,12 +2225,15 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {
         hipLaunchKernelGGL(plan_gauss_build_kernel, dim3(fused_blocks), dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 1023) / 1024) : 0u)), dim3(256), 0,
-                           stream, a);
-        hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? s.scan_blocks : 0u)),
+        const uint32_t count_wgs = coarse ? s.h_wgs : (uint32_t)((M + 1023) / 1024);
+        hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? count_wgs : 0u)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? a.s_scan_blocks : 0u)),
                            dim3(256), 0, stream, a);
         hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (do_samples ? (uint32_t)((M + 255) / 256) : 0u)), dim3(256), 0,
                            stream, a);
+        if (coarse)
+            hipLaunchKernelGGL(samples_binsort_kernel, dim3(SAMPLES_COARSE_BINS), dim3(1024), s.cells_per_bin * sizeof(uint32_t),
+                               stream, a);
     }
     if (do_plan && build_lists) {
         ListArgs la{};
@@ -1986,7 +2247,9 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
         la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
         hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)), dim3(256), 0, stream, la);
     }
-    return launch_status();
+    const int rc = launch_status();
+    if (do_samples && rc == PIGS_OK && order == 0) samples_note_order(s, sws, stream);
+    return rc;
 }
 
 // ---- the Gaussian grid alone, for the neighbour lists of aggregate_neighbors (aggregate.hip): the
@@ -2020,14 +2283,15 @@ int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags
                float q_max, float q_max_backward, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream) {
     return run_build((flags & 1) != 0, true, (flags & 2) != 0, (flags & 4) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, q_max_backward, means, conics, values,
-                     samples, stream);
+                     samples, stream, true, (flags & 8) ? 1 : (flags & 16) ? 2 : 0);
 }
 
 template <int C>
 static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, float* const* out, hipStream_t stream,
                           const Resid<float>& rz) {
     // + the helper workgroups of the TILE_MODE_POINTS tiles (they leave at once when the plan queued none)
-    const dim3 grid((sv.ntiles + 3) / 4 + POINT_HELPER_BLOCKS), block(256);
+    const dim3 grid((sv.ntiles + PIGS_FWD_WG_WAVES - 1) / PIGS_FWD_WG_WAVES + POINT_HELPER_BLOCKS * 4 / PIGS_FWD_WG_WAVES),
+        block(64 * PIGS_FWD_WG_WAVES);
     clear_hip_error();
 #define PIGS_CASE(MK)                                                                                          \
     case MK:                                                                                                   \

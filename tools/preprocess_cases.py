@@ -27,7 +27,11 @@ else:
 pts = pts.cuda()
 res = {}
 with torch.no_grad():
+    only = sys.argv[3] if len(sys.argv) > 3 else None          # "cold" / "warm": that loop only (per-kernel profiles)
     for name, reuse in (("cold", False), ("warm", True)):
+        if only and name != only:
+            res[name] = float("nan")
+            continue
         s = GaussianSampler(False, fuse="all", backend="binned", reuse_samples=reuse)
 
         def step():
