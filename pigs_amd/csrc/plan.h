@@ -146,8 +146,11 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // records, runs of a workgroup's points of one bin are contiguous); one workgroup per bin then counting-sorts
 // its segment by fine cell in LDS into the final array -- writes that stay inside a ~50 KB window.  One more
 // launch, two more passes over the points, no global atomics.
+#ifndef PIGS_HIST_WGS
+#define PIGS_HIST_WGS 1024
+#endif
 constexpr uint32_t SAMPLES_COARSE_BINS = 256;      // = threads of a build workgroup (one bin per thread where bins are walked)
-constexpr uint32_t SAMPLES_MAX_HIST_WGS = 1024;    // workgroups (chunks of the point array) of the coarse histogram
+constexpr uint32_t SAMPLES_MAX_HIST_WGS = PIGS_HIST_WGS;    // workgroups (chunks of the point array) of the coarse histogram
 constexpr uint32_t SAMPLES_MAX_CELLS_PER_BIN = 12288;      // LDS counters of the per-bin sort (48 KB)
 struct STmp {                  // a point on its way through the coarse-bin path
     float x, y;
@@ -160,7 +163,7 @@ struct SamplesLayout {
     uint32_t ntiles;           // ceil(M / 64)
     // coarse-bin path
     uint32_t cells_per_bin;    // fine cell ids per coarse bin: bin = id / cells_per_bin < SAMPLES_COARSE_BINS
-    uint32_t h_chunk;          // points per histogram workgroup (a multiple of 1024)
+    uint32_t h_chunk;          // points per histogram workgroup (a multiple of 2048)
     uint32_t h_wgs;            // histogram workgroups (a multiple of 4: the matrix is whole scan blocks)
     uint32_t h_scan_blocks;    // = SAMPLES_COARSE_BINS * h_wgs / PLAN_SCAN_BLOCK
     size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_skey, off_spts, off_hist, off_hagg, off_hstarts,
@@ -188,8 +191,9 @@ inline SamplesLayout make_samples_layout(int64_t M) {
     p.off_spts = o;     o = align_up(o + sizeof(SPoint) * (size_t)M, 256);
     // coarse-bin path: the (bin, workgroup) count matrix, its scan, the temporary array
     p.cells_per_bin = (p.scells_cap + SAMPLES_COARSE_BINS - 1) / SAMPLES_COARSE_BINS;
-    const int64_t chunks = (M + 1023) / 1024;
-    p.h_chunk = (uint32_t)((chunks + SAMPLES_MAX_HIST_WGS - 1) / SAMPLES_MAX_HIST_WGS) * 1024u;
+    // chunks of 2 048 points (what the scatter's LDS stage holds) up to 2 M points, longer ones beyond
+    const int64_t chunks = (M + 2047) / 2048;
+    p.h_chunk = (uint32_t)((chunks + SAMPLES_MAX_HIST_WGS - 1) / SAMPLES_MAX_HIST_WGS) * 2048u;
     p.h_wgs = (uint32_t)(((M + p.h_chunk - 1) / p.h_chunk + 3) / 4 * 4);
     p.h_scan_blocks = SAMPLES_COARSE_BINS * p.h_wgs / PLAN_SCAN_BLOCK;
     p.off_hist = o;     o = align_up(o + sizeof(uint32_t) * (size_t)p.h_scan_blocks * PLAN_SCAN_BLOCK, 256);
