@@ -7,6 +7,10 @@
 #ifndef PIGS_TRAV_STEPS
 #define PIGS_TRAV_STEPS 2     // candidate steps whose box records are in flight together (2, 4, 8 measured equal)
 #endif
+// (Also measured and dropped: the candidates of ALL row ranges packed into chunks of 256 -- a range holds 20-40
+// Gaussians at C3, so a step of 64 lanes is 40 % full and the ~12 ranges around a block take 6 dependent round
+// trips where a packed walk takes 1-2: the lane -> (range, offset) mapping cost more than the round trips it
+// saved, list build 21.2 vs 20.4 us; with the survivors dropped -- the walk alone -- 12.0 vs 10.8 us.)
 
 namespace pigs {
 
@@ -207,7 +211,7 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
                 }
             }
             // one call site (the exact stage and everything the caller does per batch is inlined here once)
-            if (cn > CCAP - 64 * PIGS_TRAV_STEPS || !have) exact_stage();
+            if (cn > CCAP - 64 * PIGS_TRAV_STEPS || (!have && cn > 0)) exact_stage();
         }
     }
 }

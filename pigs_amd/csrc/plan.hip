@@ -1071,9 +1071,15 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
             lds.sb[k] = make_float4(B.x, e.nb_c, e.nb_a, __builtin_bit_cast(float, j));
         }
         sn += __builtin_popcountll(mask);
+#ifdef PIGS_LISTS_PROBE_NO_FLUSH          // probe build: the traversal alone (survivors dropped)
+        if (sn > SURV_CAP - 64) sn = 0;
+#else
         if (sn > SURV_CAP - 64) flush();
+#endif
     });
+#ifndef PIGS_LISTS_PROBE_NO_FLUSH
     if (sn > 0) flush();
+#endif
 
     // A tile list that does not fit while the four group lists do (64 scattered points of a sparse
     // region share few Gaussians: up to 4 x cap distinct ones) is no reason to give the lists up: the
