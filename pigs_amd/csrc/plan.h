@@ -215,7 +215,7 @@ struct PlanLayout {
     uint32_t ntiles;           // ceil(M / 64)
     uint32_t list_cap;         // entries per list slab (one tile list + four group lists per tile), multiple of 16
     size_t off_params, off_counts, off_agg, off_starts, off_gkey, off_rec, off_box, off_g2o, off_gacc, off_hdr,
-        off_ptiles, off_tlist, off_glist, total_bytes;
+        off_ptiles, off_tlist, off_glist, off_stage, total_bytes;
 };
 
 // Counter spacing of a level with `cells` cells: device-scope atomics on one 128-byte line
@@ -272,6 +272,9 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_ptiles = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles, 256);           // queue of the TILE_MODE_POINTS tiles
     p.off_tlist = o;    o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles * p.list_cap, 256);
     p.off_glist = o;    o = align_up(o + sizeof(uint32_t) * 4 * (size_t)p.ntiles * p.list_cap, 256);
+    // one 32-byte record per sample point, in the CALLER's order: what points that arrive in no order send their
+    // outputs / fetch their incoming gradients through (STAGE_* below); untouched for lattices
+    p.off_stage = o;    o = align_up(o + 32 * (size_t)M, 256);
     p.total_bytes = o;
     return p;
 }
@@ -299,6 +302,16 @@ struct PlanView {
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     float q_max;                  // list build only: the WIDE cut-off max(q_f, q_b) (the sampling kernels read params->q_f / q_b)
     float* gacc;                  // backward scratch: [8][N] sorted-order gradient sums
+    // Staging for points in no order (null: not in this launch).  A tile of such points sends its outputs to three
+    // arrays through the points' original indices: three scattered 4 / 8 / 16-byte stores per point, each of which
+    // costs the memory a whole 32-byte sector (96 MB written for 28 MB of outputs at 1 M points: forward 54 us where
+    // a lattice takes 32), and the backward fetches the incoming gradients the same way.  Staged, a point writes ONE
+    // 32-byte record at its original index -- {u, u_x, u_y, H_xx, H_xy, H_yx, H_yy, 0}, or {u, u_x, u_y, lap} --
+    // and a streaming launch behind the forward deals the records out to the output arrays (stage_to_outputs_kernel);
+    // the backward is preceded by the opposite launch (gradients_to_stage_kernel) and reads one record per point.
+    // c = 1, orders (0, 1, 2) or (0, 1, trace); chosen by the library when it remembers the point set's size as
+    // unordered (plan.hip, samples_take_coarse).
+    float4* stage;
 };
 
 // ---- grid geometry derived (identically by every thread) from the sample bounding box ----

@@ -1430,6 +1430,16 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
     using L = FwdLayout<2, C, MASK>;
     constexpr int U = PIGS_FWD_UNROLL;
     constexpr uint32_t FW = PIGS_FWD_WG_WAVES;
+    // staged outputs (PlanView::stage): one record per point at its original index instead of the three stores
+    auto stage_store = [&](const float* acc, uint32_t m) {
+        if constexpr (C == 1 && MASK == 7) {
+            pv.stage[2 * (size_t)m] = make_float4(acc[L::O0], -acc[L::O1], -acc[L::O1 + 1], acc[L::O2]);
+            pv.stage[2 * (size_t)m + 1] = make_float4(acc[L::O2 + 1], acc[L::O2 + 1], acc[L::O2 + 2], 0.f);
+        } else if constexpr (C == 1 && MASK == 19) {
+            pv.stage[2 * (size_t)m] = make_float4(acc[L::O0], -acc[L::O1], -acc[L::O1 + 1], acc[L::O2]);
+        }
+    };
+    constexpr bool CAN_STAGE = C == 1 && (MASK == 7 || MASK == 19);
     __shared__ FwdLds lds_all[FW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1461,7 +1471,10 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
             }
-            if (i == 0 && valid) fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
+            if (i == 0 && valid) {
+                if (CAN_STAGE && pv.stage) stage_store(acc, sp.m);
+                else fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
+            }
         }
         return;
     }
@@ -1589,7 +1602,9 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
     const uint32_t m_other = (uint32_t)__shfl_xor((int)sp.m, 1);
     const uint32_t dist = sp.m > m_other ? sp.m - m_other : m_other - sp.m;
     const bool stream = __builtin_popcountll(__ballot(valid && dist == 1u)) >= 48;
-    if (valid) {
+    if (CAN_STAGE && pv.stage) {
+        if (valid) stage_store(acc, sp.m);
+    } else if (valid) {
         if (stream) {
             fwd_store<float, 2, C, MASK, true>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
             asm volatile("" ::: "memory");       // keeps the two branches' stores apart: merged into a common tail they lose the hint
@@ -1784,11 +1799,25 @@ template <int C, int MASK>
 __device__ __forceinline__ void load_tile_point(const SamplesView& sv, uint32_t tile, int lane, const float* __restrict__ G0p,
                                                 const float* __restrict__ G1p, const float* __restrict__ G2p,
                                                 const float* __restrict__ G3p, const Resid<float>& rz, SPoint& sp, bool& valid,
-                                                Gsym<float, 2, C, (MASK == ORDR ? ORDR_AS : MASK)>& G) {
+                                                Gsym<float, 2, C, (MASK == ORDR ? ORDR_AS : MASK)>& G,
+                                                const float4* __restrict__ stage = nullptr) {
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
     valid = m < sv.M;
     sp = sv.spts[valid ? m : sv.M - 1];
-    if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
+    if constexpr (C == 1 && (MASK == 7 || MASK == 19)) {
+        if (stage) {        // the incoming gradients of this point as one record (gradients_to_stage_kernel)
+            const float4 a = stage[2 * (size_t)sp.m];
+            G.g0[0] = a.x; G.g1[0][0] = a.y; G.g1[1][0] = a.z;
+            if constexpr (MASK == 7) {
+                const float4 b = stage[2 * (size_t)sp.m + 1];
+                G.g2[0][0] = a.w; G.g2[1][0] = b.x; G.g2[2][0] = b.y;
+            } else {
+                G.g2[0][0] = a.w; G.g2[1][0] = 0.f; G.g2[2][0] = a.w;
+            }
+        } else {
+            G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
+        }
+    } else if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
     else G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
     if (!valid) {
 #pragma unroll
@@ -1814,7 +1843,7 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
     SPoint sp;
     bool valid;
     Gsym<float, 2, C, EM> G;
-    load_tile_point<C, MASK>(sv, tile, lane, G0p, G1p, G2p, G3p, rz, sp, valid, G);
+    load_tile_point<C, MASK>(sv, tile, lane, G0p, G1p, G2p, G3p, rz, sp, valid, G, pv.stage);
     const float s[2] = {sp.x, sp.y};
     if (lane < 2) lds.t.rec[BWD_STEP][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     // A tile that fell back to record ranges has no masks: they are found entry by entry against the
@@ -2085,6 +2114,45 @@ __global__ __launch_bounds__(256) void plan_unpermute_kernel(PlanView pv, float*
 }
 
 // ------------------------------------------------------------------------------------------
+// staging launches (PlanView::stage): thread = point in the CALLER's order, everything coalesced
+// ------------------------------------------------------------------------------------------
+template <int MASK>
+__global__ __launch_bounds__(256) void stage_to_outputs_kernel(const float4* __restrict__ stage, uint32_t M, float* __restrict__ o0,
+                                                               float* __restrict__ o1, float* __restrict__ o2) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float4 a = stage[2 * (size_t)m];
+    if (o0) __builtin_nontemporal_store(a.x, &o0[m]);
+    if (o1) { __builtin_nontemporal_store(a.y, &o1[2 * (size_t)m]); __builtin_nontemporal_store(a.z, &o1[2 * (size_t)m + 1]); }
+    if constexpr (MASK == 7) {
+        const float4 b = stage[2 * (size_t)m + 1];
+        if (o2) {
+            float* h = o2 + 4 * (size_t)m;
+            __builtin_nontemporal_store(a.w, h); __builtin_nontemporal_store(b.x, h + 1);
+            __builtin_nontemporal_store(b.y, h + 2); __builtin_nontemporal_store(b.z, h + 3);
+        }
+    } else {
+        if (o2) __builtin_nontemporal_store(a.w, &o2[m]);
+    }
+}
+// the incoming gradients as Gsym holds them: {g0, g1x, g1y, g2_xx}, {g2_xy + g2_yx, g2_yy, 0, 0} (null arrays: zero)
+template <int MASK>
+__global__ __launch_bounds__(256) void gradients_to_stage_kernel(float4* __restrict__ stage, uint32_t M, const float* __restrict__ G0,
+                                                                 const float* __restrict__ G1, const float* __restrict__ G2) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float g0 = G0 ? G0[m] : 0.f;
+    const float2 g1 = G1 ? ((const float2*)G1)[m] : make_float2(0.f, 0.f);
+    if constexpr (MASK == 7) {
+        const float4 g2 = G2 ? ((const float4*)G2)[m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        stage[2 * (size_t)m] = make_float4(g0, g1.x, g1.y, g2.x);
+        stage[2 * (size_t)m + 1] = make_float4(0.f + g2.y + g2.z, g2.w, 0.f, 0.f);
+    } else {
+        stage[2 * (size_t)m] = make_float4(g0, g1.x, g1.y, G2 ? G2[m] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static bool samples_supported(int64_t M) { return M >= 1 && M < (1LL << 31) - 64; }
@@ -2120,6 +2188,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) v.level_off[l] = p.level_off[l];
     v.q_max = q_max;
     v.gacc = (float*)(b + p.off_gacc);
+    v.stage = (float4*)(b + p.off_stage);
     return v;
 }
 
@@ -2221,6 +2290,15 @@ static bool stream_capturing(hipStream_t stream) {
     return st != hipStreamCaptureStatusNone;
 }
 
+static void hint_poll(OrderHint& h) {           // g_hint_mu held
+    if (!h.pending) return;
+    const hipError_t q = hipEventQuery(h.ev);
+    (void)hipGetLastError();          // hipErrorNotReady is an answer, not a failure
+    if (q == hipSuccess) {
+        h.pending = false;
+        if (h.host[1] > 0u) h.coarse = (uint64_t)h.host[0] * 100u > (uint64_t)h.host[1] * 55u;
+    }
+}
 // order: 0 = ask the memory, 1 = one pass, 2 = coarse bins
 static bool samples_take_coarse(const SamplesLayout& s, int order, hipStream_t stream) {
     if (s.cells_per_bin > SAMPLES_MAX_CELLS_PER_BIN) return false;
@@ -2235,14 +2313,7 @@ static bool samples_take_coarse(const SamplesLayout& s, int order, hipStream_t s
     std::lock_guard<std::mutex> lock(g_hint_mu);
     OrderHint* h = hint_entry(dev, s.M, false);
     if (!h) return false;
-    if (h->pending && !stream_capturing(stream)) {
-        const hipError_t q = hipEventQuery(h->ev);
-        (void)hipGetLastError();          // hipErrorNotReady is an answer, not a failure
-        if (q == hipSuccess) {
-            h->pending = false;
-            if (h->host[1] > 0u) h->coarse = (uint64_t)h->host[0] * 100u > (uint64_t)h->host[1] * 55u;
-        }
-    }
+    if (!stream_capturing(stream)) hint_poll(*h);
     return h->coarse;
 }
 
@@ -2264,20 +2335,32 @@ static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t st
     (void)hipGetLastError();
 }
 
+// The sampling launches' question (staging, PlanView::stage): did the point set of this size arrive in no order?
+// A pending statistic is looked at here too -- a point set that is built once and sampled many times (fixed random
+// collocation points) never comes back to samples_take_coarse -- unless the stream is being captured.
+static bool points_unordered(int64_t M, hipStream_t stream) {
+    if (const char* e = getenv("PIGS_STAGE")) return e[0] == '1';          // tests / A-B runs: staging on or off whatever the memory and the size
+    if (M < COARSE_MIN_POINTS) return false;
+    if (const char* e = getenv("PIGS_SAMPLES_ORDER")) return !strcmp(e, "unordered");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const bool cap = stream_capturing(stream);
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    for (auto& h : g_hints)
+        if (h.device == dev && h.M == M) {
+            if (!cap) hint_poll(h);
+            return h.coarse;
+        }
+    return false;
+}
+
 int samples_order_hint(int64_t M) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
     std::lock_guard<std::mutex> lock(g_hint_mu);
     OrderHint* h = hint_entry(dev, M, false);
     if (!h) return -1;
-    if (h->pending) {
-        const hipError_t q = hipEventQuery(h->ev);
-        (void)hipGetLastError();
-        if (q == hipSuccess) {
-            h->pending = false;
-            if (h->host[1] > 0u) h->coarse = (uint64_t)h->host[0] * 100u > (uint64_t)h->host[1] * 55u;
-        }
-    }
+    hint_poll(*h);
     return h->coarse ? 1 : 0;
 }
 
@@ -2396,11 +2479,15 @@ int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags
 }
 
 template <int C>
-static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, float* const* out, hipStream_t stream,
+static int plan_forward_c(const PlanView& pv_in, const SamplesView& sv, int mask, float* const* out, hipStream_t stream,
                           const Resid<float>& rz) {
     // + the helper workgroups of the TILE_MODE_POINTS tiles (they leave at once when the plan queued none)
     const dim3 grid((sv.ntiles + PIGS_FWD_WG_WAVES - 1) / PIGS_FWD_WG_WAVES + POINT_HELPER_BLOCKS * 4 / PIGS_FWD_WG_WAVES),
         block(64 * PIGS_FWD_WG_WAVES);
+    // points that arrive in no order send their outputs through the staging records (PlanView::stage)
+    PlanView pv = pv_in;
+    const bool staged = C == 1 && (mask == 7 || mask == 19) && points_unordered(sv.M, stream);
+    if (!staged) pv.stage = nullptr;
     clear_hip_error();
 #define PIGS_CASE(MK)                                                                                          \
     case MK:                                                                                                   \
@@ -2412,14 +2499,28 @@ static int plan_forward_c(const PlanView& pv, const SamplesView& sv, int mask, f
         default: return PIGS_ERR_UNSUPPORTED;
     }
 #undef PIGS_CASE
+    if (staged) {
+        const dim3 g2((sv.M + 255) / 256), b2(256);
+        if (mask == 7) hipLaunchKernelGGL(stage_to_outputs_kernel<7>, g2, b2, 0, stream, pv.stage, sv.M, out[0], out[1], out[2]);
+        else hipLaunchKernelGGL(stage_to_outputs_kernel<19>, g2, b2, 0, stream, pv.stage, sv.M, out[0], out[1], out[2]);
+    }
     return launch_status();
 }
 
 template <int C>
-static int plan_backward_c(const PlanView& pv, const SamplesView& sv, int mask, const float* const* g, float* gm,
+static int plan_backward_c(const PlanView& pv_in, const SamplesView& sv, int mask, const float* const* g, float* gm,
                            float* gc, float* gv, hipStream_t stream, const Resid<float>& rz) {
     const dim3 grid((sv.ntiles + 3) / 4 + POINT_HELPER_BLOCKS), block(256);
+    // points that arrive in no order fetch their incoming gradients from the staging records (PlanView::stage)
+    PlanView pv = pv_in;
+    const bool staged = C == 1 && (mask == 7 || mask == 19) && !PIGS_BWD_BLOCK && points_unordered(sv.M, stream);
+    if (!staged) pv.stage = nullptr;
     clear_hip_error();
+    if (staged) {
+        const dim3 g2((sv.M + 255) / 256), b2(256);
+        if (mask == 7) hipLaunchKernelGGL(gradients_to_stage_kernel<7>, g2, b2, 0, stream, pv.stage, sv.M, g[0], g[1], g[2]);
+        else hipLaunchKernelGGL(gradients_to_stage_kernel<19>, g2, b2, 0, stream, pv.stage, sv.M, g[0], g[1], g[2]);
+    }
 #if PIGS_BWD_BLOCK
     const dim3 bgrid((((sv.ntiles + 3) / 4) + 3) / 4 + POINT_HELPER_BLOCKS);
 #define PIGS_CASE(MK)                                                                                             \

@@ -150,3 +150,58 @@ def test_captured_step_on_the_coarse_bin_build(Sampler):
             s2.preprocess(*step.inputs[:2], None, step.inputs[2], new)
             for a, b in zip(outs, s2.sample((0, 1, 2))):
                 assert rel(a, b.cpu().double().numpy()) < TOL
+
+
+class forced_stage:
+    """PIGS_STAGE for the sampling launches inside the block (read at every launch)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("PIGS_STAGE")
+        os.environ["PIGS_STAGE"] = "1" if self.on else "0"
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("PIGS_STAGE", None)
+        else:
+            os.environ["PIGS_STAGE"] = self.old
+
+
+@pytest.mark.parametrize("orders", [(0, 1, 2), (0, 1, "lap"), (0, 1), (2,), (1, "lap")])
+def test_staged_outputs_and_gradients_match_the_direct_path(Sampler, orders):
+    """Points in no order send their outputs / fetch their incoming gradients through one 32-byte record per point
+    (PlanView::stage, plan.h) instead of three scattered accesses.  Staging forced on a shuffled point set with
+    ragged last tile, every combination of requested outputs (the launches cover the subset with the (0, 1, 2) /
+    (0, 1, trace) kernels: unrequested outputs and absent gradients are null there): outputs and gradients equal
+    to the direct path's up to float32 summation order, outputs against the oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(21)
+    means, con, values = random_gaussians(rng, 1500, 1, log_sigma_mean=-3.1, log_sigma_std=0.4)
+    pts = rng.uniform(-1, 1, (50 * 64 + 29, 2))
+    res = {}
+    for on in (False, True):
+        with forced_stage(on):
+            t = [dev32(a) for a in (means, values, con, pts)]
+            for x in t[:3]:
+                x.requires_grad_(True)
+            s = Sampler(True, backend="binned")
+            s.preprocess(t[0], t[1], None, t[2], t[3])
+            outs = s.sample(orders)
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            rs = [torch.randn(o.shape, generator=gen).cuda() for o in outs]
+            sum((o * r).sum() for o, r in zip(outs, rs)).backward()
+            res[on] = ([o.detach().clone() for o in outs], [x.grad.clone() for x in t[:3]], rs)
+    for a, b in zip(res[False][0], res[True][0]):       # (two builds: the order inside a cell, hence the lists, may differ)
+        assert rel(b, a.cpu().double().numpy()) < 2e-6
+    for a, b in zip(res[False][1], res[True][1]):
+        assert rel(b, a.cpu().double().numpy()) < 2e-6
+    args = [np.asarray(x, dtype=np.float64) for x in (means, con, values, pts)]
+    want = c_oracle.forward(*args, orders=tuple(o for o in orders if o != "lap") + ((2,) if "lap" in orders else ()))
+    for o, out in zip(orders, res[True][0]):
+        if o == "lap":
+            exp = want[2][:, 0, 0, :] + want[2][:, 1, 1, :]
+        else:
+            exp = want[o]
+        assert rel(out, exp) < TOL, (o, rel(out, exp))

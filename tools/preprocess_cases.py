@@ -54,4 +54,14 @@ with torch.no_grad():
     for _ in range(50):
         S.forward_raw(m, v, c, sm, 7, s._plan)
     e1.record(); torch.cuda.synchronize()
-print(f"{case:9s} kappa={kappa}: cold {res['cold']:7.1f} us/step  warm {res['warm']:7.1f} us/step  forward kernel {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us", flush=True)
+    M = pts.shape[0]
+    go = [torch.randn((M,) + (2,) * k + (1,), device="cuda") for k in range(3)] + [None, None]
+    for _ in range(3):
+        S.backward_raw(m, v, c, sm, go, 7, s._plan)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record()
+    for _ in range(20):
+        S.backward_raw(m, v, c, sm, go, 7, s._plan)
+    b1.record(); torch.cuda.synchronize()
+print(f"{case:9s} kappa={kappa}: cold {res['cold']:7.1f} us/step  warm {res['warm']:7.1f} us/step  forward kernel {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us"
+      f"  backward kernels {b0.elapsed_time(b1) / 20 * 1e3:7.1f} us", flush=True)
