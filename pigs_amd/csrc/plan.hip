@@ -590,10 +590,12 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
 // Last launch of the coarse-bin path: one workgroup per coarse bin counting-sorts the bin's segment of the
 // temporary array by fine cell into the final array.  LDS: one counter per fine cell of the bin (count, then
 // -- scanned in place -- cursor).  Segments up to 8 192 points are read once (registers); the writes stay inside
-// the segment.  Order inside a cell: as the atomics fall (as in the one-pass build).  (SUB = 16 also orders the
-// points of a cell by a 4 x 4 Z-order of sub-cells: measured, 41.9 -> 41.0 Gaussians per point at 1 M random
-// points -- the halves of a Z-order are full-width strips, a group that straddles two cells still spans both --
-// not worth 16x the counters; SUB = 1 is what runs.)
+// the segment.  SUB = 16 (where the LDS holds 16 counters per cell: up to ~2 M points) also orders the points of a
+// cell along the cell path continued into the cell (key_of below): a group is 16 consecutive sorted points, cells
+// of unordered points hold 16 +- 4, so most groups straddle two cells, and with a cell's points in no order such
+// a group's box spans both cells whole.  (A 4 x 4 Z-order of sub-cells was tried first: 41.9 -> 41.0 Gaussians
+// per point at 1 M random points -- the halves of a Z-order are full-width strips.)  Order inside a key: as the
+// atomics fall.
 template <int SUB>
 __global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
     extern __shared__ uint32_t cnt[];       // [cells_per_bin * SUB]
@@ -610,11 +612,29 @@ __global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
     auto key_of = [&](const uint4 t) -> uint32_t {
         uint32_t k = (t.w - id0) * (uint32_t)SUB;
         if constexpr (SUB == 16) {
-            // position inside the cell, from the same clamped cell coordinates the cell id came from
+            // The point's place on the cell path continued INTO the cell: the path through a 4 x 4 block of cells is the
+            // order-2 Hilbert curve (sample_cell_id), whose order-4 refinement runs through the 4 x 4 sub-cells of every
+            // cell from the side the path enters the cell to the side it leaves (its top nibble IS the cell's index
+            // inside the block) -- so consecutive points stay neighbours across a cell border.  Coordinates: 4 bits per
+            // axis inside the block, from the same clamped cell coordinates the cell id came from; x mirrored in the
+            // right-to-left block rows, as there.
             const float u = clampf((__uint_as_float(t.x) - sg.ox) * sg.inv_w, 0.f, (float)(sg.nx - 1));
             const float v = clampf((__uint_as_float(t.y) - sg.oy) * sg.inv_w, 0.f, (float)(sg.ny - 1));
-            const uint32_t sx = min(3u, (uint32_t)((u - floorf(u)) * 4.f)), sy = min(3u, (uint32_t)((v - floorf(v)) * 4.f));
-            k += (sx & 1u) | ((sy & 1u) << 1) | ((sx >> 1) << 2) | ((sy >> 1) << 3);      // NaN coordinates: 0
+            const int cx = (int)u, cy = (int)v;
+            uint32_t x = (uint32_t)(cx & 3) * 4u + min(3u, (uint32_t)((u - (float)cx) * 4.f));
+            uint32_t y = (uint32_t)(cy & 3) * 4u + min(3u, (uint32_t)((v - (float)cy) * 4.f));
+            if ((cy >> 2) & 1) x = 15u - x;
+            uint32_t d = 0;
+#pragma unroll
+            for (uint32_t sbit = 8u; sbit > 0u; sbit >>= 1) {
+                const uint32_t rx = (x & sbit) ? 1u : 0u, ry = (y & sbit) ? 1u : 0u;
+                d += sbit * sbit * ((3u * rx) ^ ry);
+                if (ry == 0u) {
+                    if (rx == 1u) { x = 15u - x; y = 15u - y; }
+                    const uint32_t tt = x; x = y; y = tt;
+                }
+            }
+            k += d & 15u;      // NaN coordinates: cell (0, 0), sub-cell 0
         }
         return k;
     };
@@ -2423,8 +2443,12 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
         hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (do_samples ? scatter_wgs : 0u)), dim3(256),
                            staged ? s.h_chunk * sizeof(uint4) + 2 * SAMPLES_COARSE_BINS * sizeof(uint32_t) : 0, stream, a);
         if (coarse) {
-            hipLaunchKernelGGL(samples_binsort_kernel<1>, dim3(SAMPLES_COARSE_BINS), dim3(1024),
-                               s.cells_per_bin * sizeof(uint32_t), stream, a);
+            if (s.cells_per_bin * 16u <= SAMPLES_MAX_CELLS_PER_BIN)      // the LDS holds 16 sub-cell counters per cell
+                hipLaunchKernelGGL(samples_binsort_kernel<16>, dim3(SAMPLES_COARSE_BINS), dim3(1024),
+                                   s.cells_per_bin * 16u * sizeof(uint32_t), stream, a);
+            else
+                hipLaunchKernelGGL(samples_binsort_kernel<1>, dim3(SAMPLES_COARSE_BINS), dim3(1024),
+                                   s.cells_per_bin * sizeof(uint32_t), stream, a);
         }
     }
     if (do_plan && build_lists) {
