@@ -607,6 +607,35 @@ def main():
         except Exception as e:
             c2 = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+    unordered = None
+    if not a.no_extras and dist is None and a.workload == "c3":
+        # the same Gaussians sampled at M uniform random points (torch.rand collocation points, main_pn.py:103): the
+        # library switches to the coarse-bin samples build and to staged outputs / gradients once it has seen how a
+        # point set of this size arrives -- extra figures, not `value`
+        try:
+            gen = torch.Generator().manual_seed(3)
+            pr = (torch.rand((M, 2), generator=gen) * 2 - 1).to(dev)
+            sr, stepr = forward_only(t, pr, False)
+            srw, steprw = forward_only(t, pr, True)
+            with torch.no_grad():
+                settle(stepr)
+                dc = timed_steps(stepr, 10, 100) / 100
+                settle(steprw)
+                dw = timed_steps(steprw, 10, 100) / 100
+                mr, vr, cr, smr = srw._inputs
+                gor = [torch.randn((M,) + (2,) * k + (1,), device=dev) for k in range(3)] + [None, None]
+                kf = kernel_ms(lambda: S.forward_raw(mr, vr, cr, smr, 7, srw._plan), 10)
+                kb = kernel_ms(lambda: S.backward_raw(mr, vr, cr, smr, gor, 7, srw._plan), 5)
+            from pigs_amd import _lib
+            unordered = {"points": "uniform random in [-1, 1]^2, M = %d" % M, "cold_ms_per_step": dc * 1e3, "warm_ms_per_step": dw * 1e3,
+                         "forward_launches_ms": kf, "backward_launches_ms": kb, "value_cold": M / dc,
+                         "library_took": {1: "coarse-bin samples build, staged outputs and gradients", 0: "one-pass samples build",
+                                          -1: "no record"}[_lib.load().pigs_samples_order_hint(M)],
+                         "what": "cold / warm step as `value` / `value_warm_plan`; forward / backward: all launches of one "
+                                 "sampler.sample((0, 1, 2)) / its backward on a built plan (tile kernel + the staging launch)"}
+        except Exception as e:
+            unordered = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     line = {
         "metric": "sample-points/sec (fwd + 1st + 2nd derivatives, fused)", "value": value,
         "unit": "sample-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -620,7 +649,7 @@ def main():
         "host_issue_ms_per_step": host_cold * 1e3,
         "preheat_ms": preheat_ms, "value_warm_plan": warm["value"], "warm_plan": warm,
         "roofline": roofline, "roofline_bwd": roofline_bwd, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
-        "kappa_1_3": kappa13, "small": small, "c2": c2, "host": sampler.host,
+        "kappa_1_3": kappa13, "small": small, "c2": c2, "unordered_points": unordered, "host": sampler.host,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(gs, pts)

@@ -130,7 +130,11 @@ size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsuppor
  * behind the build (nobody waits); the next build of the same M takes the path the last completed copy
  * recommends (more than 0.55 runs per point: coarse bins).  Captured builds neither ask nor copy.
  * PIGS_SAMPLES_ORDER=ordered|unordered in the environment overrules the memory (tests), as do the
- * PIGS_BUILD_POINTS_* flags of pigs_plan_build. */
+ * PIGS_BUILD_POINTS_* flags of pigs_plan_build.
+ * The same memory decides how pigs_plan_forward / pigs_plan_backward move the outputs / incoming gradients of
+ * c = 1, orders (0, 1, 2) or (0, 1, trace) launches: directly through the points' original indices (lattices:
+ * runs of consecutive indices), or -- points in no order -- through one 32-byte record per point in the plan
+ * workspace and a streaming launch that deals the records out / gathers them (PIGS_STAGE=0|1 overrules). */
 int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream);
 /* what the library currently remembers for builds of M points on the current device: 1 = coarse bins,
  * 0 = one pass, -1 = nothing yet (introspection for tools and tests) */
