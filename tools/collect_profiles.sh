@@ -11,12 +11,14 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 stats() {   # name, program args...
     name=$1; shift
+    rm -rf $out/raw_$name
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw_$name -- python3 "$@" > $out/$name.log 2>&1
     cp $(find $out/raw_$name -name '*kernel_stats.csv' | head -1) $out/${tag}_${name}_kernel_stats.csv
     echo "== $name"; tail -1 $out/$name.log | cut -c1-300
 }
 pmc() {     # name, counters, prof_step args...
     name=$1; set_=$2; shift; shift
+    rm -rf $out/pmc_$name
     rocprofv3 --kernel-trace --pmc $set_ --output-format csv -d $out/pmc_$name -- python3 $root/tools/prof_step.py "$@" > $out/pmc_$name.log 2>&1
     cp $(find $out/pmc_$name -name '*counter_collection.csv' | head -1) $out/${tag}_c3_k0.5_pmc_$name.csv
     echo "== pmc $name done"

@@ -24,7 +24,9 @@ if "--key" in sys.argv:
     args.remove(key)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in args:
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges every collection's raw files into the same local directory: only the newest pass counts
+    found = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in found[-1:]:
         per_dispatch = collections.defaultdict(float)     # (dispatch, kernel, counter) -> sum over instances
         for r in csv.DictReader(open(f)):
             per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"], r["Counter_Name"])] += float(r["Counter_Value"])
