@@ -71,3 +71,18 @@ def test_sampler_rejects_cpu_tensors(hip_lib):
         s.preprocess(means, values, con, con, pts)
     with pytest.raises(RuntimeError, match="preprocess"):
         s.sample_gaussians()
+
+
+def test_workspace_sizes_cover_the_coarse_bin_build_and_the_staging(hip_lib):
+    """Sizes are pure functions of (N, M, c): the samples workspace holds the coarse-bin build's count matrix,
+    its scan and the 16-byte temporary records (include/pigs_amd.h, pigs_samples_build), the plan workspace one
+    32-byte staging record per sample point; both grow monotonically with M."""
+    last_s = last_p = 0
+    for M in (1, 63, 64, 1000, 32768, 1 << 20, (1 << 20) + 5):
+        sb = hip_lib.pigs_samples_workspace_bytes(M)
+        pb = hip_lib.pigs_plan_workspace_bytes(4096, M, 1)
+        assert sb >= (8 + 12 + 16) * M and pb >= (160 + 32) * M
+        assert sb >= last_s and pb >= last_p
+        last_s, last_p = sb, pb
+    assert hip_lib.pigs_samples_workspace_bytes(0) == 0          # unsupported sizes report 0
+    assert hip_lib.pigs_samples_order_hint(12345) == -1          # nothing remembered (and no GPU needed to ask)
