@@ -45,6 +45,8 @@ def point_sets(rng):
     yield "one point", rng.uniform(-1, 1, (1, 2))
     yield "63 points", rng.uniform(-1, 1, (63, 2))
     yield "random 5k", rng.uniform(-1, 1, (5000, 2))
+    for M in (2048, 2049, 6143):                 # whole chunks of the coarse-bin build, one point more, one point less
+        yield f"random {M}", rng.uniform(-1, 1, (M, 2))
     yield "random 70k + ragged tile", rng.uniform(-1, 1, (70 * 1024 + 37, 2))
     g = np.linspace(-1, 1, 200)
     gx, gy = np.meshgrid(g, g, indexing="xy")
