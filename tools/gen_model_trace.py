@@ -184,9 +184,12 @@ def run(problem_name, n_lattice, n_samples, epochs, timesteps, seed):
         time_samples = torch.rand(n_samples)
         samples = (torch.rand((n_samples, d)) * 2.0 - 1.0) * scale
         bc_samples = boundary_points(n_samples, scale)
-        if problem == model_pn.Problem.NAVIER_STOKES:
-            # the reference loads fitted Gaussians from files that are not in the tree (main_pn.py:39);
-            # a seeded random cloud of the same kind stands in for them
+        if problem in (model_pn.Problem.NAVIER_STOKES, model_pn.Problem.WAVE):
+            # NAVIER_STOKES: the reference loads fitted Gaussians from files that are not in the tree (main_pn.py:39);
+            # WAVE: its randomize() path fails in the reference itself (reset() concatenates a 2-channel boundary
+            # state with a 1-channel random one, model_pn.py:530).  A seeded random 2-channel cloud of the same kind
+            # stands in for both through set_initial_params (POISSON cannot be constructed at all: Model.__init__
+            # has no channel count for it, model_pn.py:417)
             n = n_lattice * n_lattice
             means = (torch.rand((n, d)) * 2.0 - 1.0) * scale
             values = torch.randn((n, 2)) * 0.2
@@ -241,7 +244,9 @@ def main():
         for name, n_lattice, n_samples, epochs, timesteps, seed in (
                 ("DIFFUSION", 12, 256, 2, 2, 1),
                 ("NAVIER_STOKES", 10, 192, 1, 2, 2),
-                ("BURGERS", 9, 128, 1, 2, 3)):
+                ("BURGERS", 9, 128, 1, 2, 3),
+                ("WAVE", 9, 128, 1, 2, 4),
+                ("TEST", 9, 128, 1, 2, 6)):
             losses = run(name, n_lattice, n_samples, epochs, timesteps, seed)
             save(os.path.join(out, f"model_pn_trace_{name.lower()}.npz"), losses)
 
