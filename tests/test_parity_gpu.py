@@ -181,6 +181,41 @@ def test_1d_call_shapes(Sampler):
     assert rel(s.sample_gaussians_laplacian(), z["out2_f64"]) < F32_TOL + input_rounding(exp[2], z["out2_f64"])
 
 
+def test_1d_training_call_conventions(Sampler):
+    """The reference's 1-D training scripts hand over covariances / conics as [N, 1, 1] (test_initialize_1d.py:54-58:
+    ``exp(scaling).reshape(-1, d, d)``, ``1.0 / covariances``) or [N, 1] (test_no_mlp_1d.py:109-113), two channels
+    (``values = rand((n, d))`` is [N, 1] there; [N, 2] here), and differentiate a loss on ``sample_gaussians()``
+    back to the raw parameters behind tanh / exp: outputs and the gradients that reach those leaves against the
+    oracle's (float64 autograd through the same chain)."""
+    rng = np.random.default_rng(3)
+    N, M = 80, 128
+    raw_means = torch.tensor(np.arctanh(np.linspace(-0.95, 0.95, N)).reshape(N, 1), dtype=torch.float32, device="cuda", requires_grad=True)
+    scaling = torch.full((N, 1), -5.0, device="cuda", requires_grad=True)
+    values = torch.tensor(rng.uniform(0, 1, (N, 2)), dtype=torch.float32, device="cuda", requires_grad=True)
+    samples = torch.tensor(rng.uniform(-1, 1, (M, 1)), dtype=torch.float32, device="cuda")
+    r = torch.tensor(rng.uniform(-1, 1, (M, 2)), dtype=torch.float32, device="cuda")
+    for shape in ((-1, 1, 1), (-1, 1)):
+        for t in (raw_means, scaling, values):
+            t.grad = None
+        means = torch.tanh(raw_means)
+        covariances = torch.exp(scaling).reshape(*shape)
+        conics = 1.0 / covariances
+        s = Sampler(True)
+        s.preprocess(means, values, covariances, conics, samples)
+        img = s.sample_gaussians()
+        assert tuple(img.shape) == (M, 2)
+        (img * r).sum().backward()
+        # the oracle on the same float32 inputs, its gradients chained by hand through tanh / exp / reciprocal
+        args = [x.detach().cpu().double().numpy() for x in (means, conics.reshape(N, 1), values, samples)]
+        exp = c_oracle.forward(*args, orders=(0,))
+        assert rel(img, exp[0]) < F32_TOL
+        gm, gc, gv = c_oracle.backward(*args, {0: r.cpu().double().numpy()})
+        m64, c64 = args[0], args[1]
+        assert rel(values.grad, gv) < 1e-5
+        assert rel(raw_means.grad, gm * (1.0 - m64 ** 2)) < 1e-5                 # d tanh
+        assert rel(scaling.grad, gc.reshape(N, 1) * (-c64)) < 1e-5             # conic = exp(-scaling)
+
+
 def test_masked_noncontiguous_inputs(Sampler):
     """model_pn.py:769: inputs arrive as boolean-mask selections / non-contiguous views."""
     z, t = load_case("random_d2_c1.npz", torch.float64)
