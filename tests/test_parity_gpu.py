@@ -73,7 +73,8 @@ def test_forward_f64_matches_reference(Sampler, name, fuse):
 def backends_for(name):
     """The reference-generated fixtures run through the dense path (what "auto" picks at their sizes) and,
     where the binned path takes the case (float32, d = 2, c <= 2), through it as well."""
-    return ["auto", "binned"] if "d2" in name or name in ("ref_test_derivatives.npz", "ref_test_gaussian_sampling.npz") else ["auto"]
+    d2 = ("ref_test_derivatives.npz", "ref_test_gaussian_sampling.npz", "ref_test_density.npz", "ref_test_torus.npz")
+    return ["auto", "binned"] if "d2" in name or name in d2 else ["auto"]
 
 
 F32_CASES = [(n, b) for n in D12 for b in backends_for(n)]

@@ -14,7 +14,8 @@ Runs ONLY in the build container, where the reference is mounted read-only at
   the comparison the reference makes at test_derivatives.py:122-124, 208-220, 340-356.
 
 Input recipes follow the reference drivers: test_gaussian_sampling.py:13-46,
-test_derivatives.py:13-70, test_1d.py:11-27, gaussians.build_full_covariances (:163-183).
+test_derivatives.py:13-70, test_1d.py:11-27, test_density.py:10-38, test_torus.py:10-33,
+gaussians.build_full_covariances (:163-183).
 ``ref_build_covariances.npz`` pins the covariance builder itself (gaussians.py:163-193).
 
 Usage:  MPLBACKEND=Agg python tools/gen_golden.py
@@ -177,6 +178,39 @@ def case_1d():
     run_case("ref_test_1d", means, values, cov.reshape(n, 1, 1), con.reshape(n, 1, 1), samples, seed=13)
 
 
+def case_density():
+    # test_density.py:10-38: a jittered 10 x 10 lattice of isotropic Gaussians (variance e^-4), values 0.5, 64^2 grid
+    nx = ny = 10
+    d = 2
+    g = torch.Generator().manual_seed(21)
+    tx = torch.linspace(-1, 1, nx, dtype=torch.float64)
+    ty = torch.linspace(-1, 1, ny, dtype=torch.float64)
+    gx, gy = torch.meshgrid((tx, ty), indexing="ij")
+    means = torch.stack((gx, gy), dim=-1).reshape(nx * ny, d) \
+        + (torch.rand((nx * ny, d), generator=g, dtype=torch.float64) * 2.0 - 1.0) * 0.1
+    scaling = torch.exp(torch.ones((nx * ny, d), dtype=torch.float64) * -4.0)
+    transform = torch.tanh(torch.zeros((nx * ny, d * (d - 1) // 2), dtype=torch.float64))
+    full_cov, full_con = ref.build_full_covariances(scaling, transform)
+    values = torch.ones((nx * ny, 1), dtype=torch.float64) * 0.5
+    samples = grid_samples(64)
+    run_case("ref_test_density", means, values, full_cov, full_con, samples[::3], seed=14)
+
+
+def case_torus():
+    # test_torus.py:10-33: ten Gaussians (variance e^-3) in a column at x = -0.95, right at the border of the 128^2
+    # sample grid.  The script's name says what the native sampler may do there (wrap around); the reference's PyTorch
+    # twin -- what these fixtures pin -- does not: dense, non-periodic sums (parity unpinned (2)).
+    n, d = 10, 2
+    ty = torch.linspace(-1, 1, n, dtype=torch.float64)
+    means = torch.stack((torch.ones(n, dtype=torch.float64) * -0.95, ty), dim=-1)
+    scaling = torch.exp(torch.ones((n, d), dtype=torch.float64) * -3.0)
+    transform = torch.zeros((n, d * (d - 1) // 2), dtype=torch.float64)
+    full_cov, full_con = ref.build_full_covariances(scaling, transform)
+    values = torch.ones((n, 1), dtype=torch.float64) * 0.5
+    samples = grid_samples(128)
+    run_case("ref_test_torus", means, values, full_cov, full_con, samples[::11], seed=15)
+
+
 def case_random(name, N, M, d, c, seed):
     g = torch.Generator().manual_seed(seed)
     means = torch.rand((N, d), generator=g, dtype=torch.float64) * 2 - 1
@@ -217,10 +251,16 @@ def main():
     if "--only-covariances" in sys.argv:      # keeps the other fixtures' bytes untouched
         case_build_covariances()
         return
+    if "--only-density-torus" in sys.argv:
+        case_density()
+        case_torus()
+        return
     case_build_covariances()
     case_gaussian_sampling()
     case_derivatives()
     case_1d()
+    case_density()
+    case_torus()
     case_random("random_d2_c2", N=97, M=301, d=2, c=2, seed=3)
     case_random("random_d2_c1", N=300, M=777, d=2, c=1, seed=4)
     case_random("random_d1_c2", N=41, M=130, d=1, c=2, seed=5)
