@@ -16,9 +16,10 @@ def pytest_configure(config):
 
 def golden_files():
     """The sampler fixtures (ref_build_covariances.npz pins the covariance builder: tests/test_covariances.py;
-    model_pn_trace_*.npz are the model call traces: tests/test_model_trace_gpu.py)."""
+    model_pn_trace_*.npz are the model call traces: tests/test_model_trace_gpu.py; ref_loss_curve_*.npz the loss
+    curves of the training loop through the reference's functions: tests/test_training_*.py)."""
     return sorted(f for f in os.listdir(GOLDEN)
-                  if f.endswith(".npz") and not f.startswith("ref_build_") and not f.startswith("model_pn_trace_"))
+                  if f.endswith(".npz") and not f.startswith(("ref_build_", "model_pn_trace_", "ref_loss_curve_")))
 
 
 @pytest.fixture(scope="session")

@@ -96,3 +96,17 @@ def test_training_loss_curve_matches_oracle(hip_lib):
     assert gpu[-1] < gpu[10]                                 # the residual decreases
     rel = np.abs(gpu - cpu) / np.maximum(np.abs(cpu), 1e-12)
     assert rel.max() < 2e-3, (rel.max(), gpu, cpu)           # fp32 trajectories stay together over 30 steps
+
+
+def test_training_loss_curve_matches_the_reference_functions(hip_lib):
+    """The same loop against tests/golden/ref_loss_curve_no_mlp.npz: the loss per step with the REFERENCE's own
+    gaussians.sample_gaussians / gaussian_derivative / gaussian_derivative2 as the sampler (tools/gen_loss_curve.py,
+    float32 on the CPU, recorded in the build container) -- BASELINE config 5's "loss-curve parity vs reference" in
+    the form that needs only the sampler."""
+    import os
+    from conftest import GOLDEN
+    from diff_gaussian_sampling import GaussianSampler
+    ref = np.load(os.path.join(GOLDEN, "ref_loss_curve_no_mlp.npz"))["losses"]
+    gpu = run_loop(GaussianSampler(False), torch.device("cuda"), steps=len(ref))
+    rel = np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-12)
+    assert rel.max() < 2e-3, (rel.max(), gpu, ref)           # float32 trajectories stay together over 30 steps
