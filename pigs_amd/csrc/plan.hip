@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             const uint32_t b = __shfl(base[k], r[k].start);
             if (i < a.M) a.skey[i] = make_uint2(id[k], b + (uint32_t)(lane - r[k].start));
         }
-        if (((blockIdx.x - gblocks) & 31u) == 0u) {      // a sample of the waves: runs per point (SampleParams::order_stat)
+        if (((blockIdx.x - gblocks) & 31u) == 0u && threadIdx.x < 64u) {      // a sample of the waves (one in 128): runs per point (SampleParams::order_stat)
             uint32_t runs = 0, pts = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2284,16 +2284,26 @@ struct OrderHint {
     uint64_t stamp = 0;
 };
 static std::mutex g_hint_mu;
-static OrderHint g_hints[8];
+static OrderHint g_hints[16];
 static uint64_t g_hint_clock = 0;
 
-static OrderHint* hint_entry(int device, int64_t M, bool create) {      // g_hint_mu held
+static void hint_poll(OrderHint& h);
+static OrderHint* hint_entry(int device, int64_t M, bool create) {      // g_hint_mu held; create: never inside a capture
     OrderHint* lru = nullptr;
     for (auto& h : g_hints) {
         if (h.device == device && h.M == M) { h.stamp = ++g_hint_clock; return &h; }
         if (!h.pending && (!lru || h.stamp < lru->stamp)) lru = &h;
     }
-    if (!create || !lru) return nullptr;
+    if (!create) return nullptr;
+    if (!lru) {
+        // every slot waits for a copy (sizes that were built once and never came back): the copies have long
+        // landed -- take note of them and give the least recently used slot away
+        for (auto& h : g_hints) {
+            hint_poll(h);
+            if (!h.pending && (!lru || h.stamp < lru->stamp)) lru = &h;
+        }
+        if (!lru) return nullptr;
+    }
     if (lru->ev && lru->device != device) {      // an event belongs to the device it was created on
         (void)hipEventDestroy(lru->ev);
         lru->ev = nullptr;

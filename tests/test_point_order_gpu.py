@@ -154,6 +154,26 @@ def test_captured_step_on_the_coarse_bin_build(Sampler):
                 assert rel(a, b.cpu().double().numpy()) < TOL
 
 
+def test_the_memory_does_not_run_out_of_slots(Sampler, hip_lib):
+    """The library remembers a handful of sizes.  Sizes that were built once and never came back leave slots
+    waiting for their statistic: a new size must still get a slot (the landed copies are noted, the least
+    recently used slot is given away) and be recognised as unordered."""
+    rng = np.random.default_rng(17)
+    means, con, values = random_gaussians(rng, 300, 1, log_sigma_mean=-3.0, log_sigma_std=0.3)
+    t = [dev32(a) for a in (means, values, con)]
+    with forced_order(None), torch.no_grad():
+        s = Sampler(False, backend="binned", reuse_samples=False)
+        for k in range(24):                              # more one-off sizes than there are slots
+            s.preprocess(t[0], t[1], None, t[2], dev32(rng.uniform(-1, 1, (40000 + 64 * k, 2))))
+        torch.cuda.synchronize()
+        M = 51111
+        p = dev32(rng.uniform(-1, 1, (M, 2)))
+        for _ in range(36):
+            s.preprocess(t[0], t[1], None, t[2], p)
+            torch.cuda.synchronize()
+        assert hip_lib.pigs_samples_order_hint(M) == 1
+
+
 class forced_stage:
     """PIGS_STAGE for the sampling launches inside the block (read at every launch)."""
 
