@@ -189,6 +189,7 @@ __global__ __launch_bounds__(NW * 64) void dense_backward_kernel(
 // lanes of a row read the same record).  The four rows of a wave meet by two shuffles, the waves in LDS, in a
 // fixed order.  (8 waves: 256 VGPRs a wave -- the widest accumulator sets fit without spilling.)
 constexpr int ROWS_WAVES = 8;
+constexpr int ROWS_CHUNK_BYTES = 36 * 1024;      // Gaussian parameters staged per chunk (1 536 Gaussians of d = 2, c = 1, float32)
 template <typename T, int D, int C, int MASK>
 __global__ __launch_bounds__(64 * ROWS_WAVES) void dense_forward_rows_kernel(
     int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics, const T* __restrict__ values,
@@ -209,27 +210,30 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void dense_forward_rows_kernel(
     T acc[L::N];
 #pragma unroll
     for (int k = 0; k < L::N; ++k) acc[k] = T(0);
-    auto load = [&](int64_t n, T* mu, T* con, T* v) {
+    // The Gaussians come through LDS, a chunk at a time: the workgroup copies the chunk's three parameter arrays in
+    // one coalesced round trip, then every (wave, row) slice walks ITS Gaussians of the chunk with row-uniform LDS
+    // reads (fetched straight from global memory, a slice's 50 Gaussians at N = 1 600 were a chain of 25
+    // dependent round trips: 12 us for 1.6 M pairs).
+    constexpr int CHUNK = ROWS_CHUNK_BYTES / (int)((D + NF + C) * sizeof(T));
+    __shared__ T smu[CHUNK * D], scon[CHUNK * NF], sval[CHUNK * C];
+    for (int64_t n0 = 0; n0 < N; n0 += CHUNK) {
+        const int cnt = (int)(N - n0 < CHUNK ? N - n0 : CHUNK);
+        if (n0 > 0) __syncthreads();                      // the previous chunk has been read by everyone
+        for (int k = threadIdx.x; k < cnt * D; k += 64 * ROWS_WAVES) smu[k] = means[n0 * D + k];
+        for (int k = threadIdx.x; k < cnt * NF; k += 64 * ROWS_WAVES) scon[k] = conics[n0 * NF + k];
+        for (int k = threadIdx.x; k < cnt * C; k += 64 * ROWS_WAVES) sval[k] = values[n0 * C + k];
+        __syncthreads();
+#pragma unroll 2
+        for (int n = wave * 4 + row; n < cnt; n += SLICES) {
+            T mu[D], con[NF], v[C];
 #pragma unroll
-        for (int k = 0; k < D; ++k) mu[k] = means[n * D + k];
+            for (int k = 0; k < D; ++k) mu[k] = smu[n * D + k];
 #pragma unroll
-        for (int k = 0; k < NF; ++k) con[k] = conics[n * NF + k];
+            for (int k = 0; k < NF; ++k) con[k] = scon[n * NF + k];
 #pragma unroll
-        for (int k = 0; k < C; ++k) v[k] = values[n * C + k];
-    };
-    // two Gaussians of the slice per iteration: their loads are in flight together
-    int64_t n = wave * 4 + row;
-    for (; n + SLICES < N; n += 2 * SLICES) {
-        T mu0[D], con0[NF], v0[C], mu1[D], con1[NF], v1[C];
-        load(n, mu0, con0, v0);
-        load(n + SLICES, mu1, con1, v1);
-        fwd_accumulate<T, D, C, MASK>(acc, s, mu0, con0, v0, &rz);
-        fwd_accumulate<T, D, C, MASK>(acc, s, mu1, con1, v1, &rz);
-    }
-    if (n < N) {
-        T mu0[D], con0[NF], v0[C];
-        load(n, mu0, con0, v0);
-        fwd_accumulate<T, D, C, MASK>(acc, s, mu0, con0, v0, &rz);
+            for (int k = 0; k < C; ++k) v[k] = sval[n * C + k];
+            fwd_accumulate<T, D, C, MASK>(acc, s, mu, con, v, &rz);
+        }
     }
 #pragma unroll
     for (int k = 0; k < L::N; ++k) {
@@ -261,7 +265,8 @@ template <typename T, int D, int C, int MASK>
 __global__ __launch_bounds__(256) void dense_backward_staged_kernel(
     int64_t N, int64_t M, const T* __restrict__ means, const T* __restrict__ conics, const T* __restrict__ values,
     const T* __restrict__ samples, const T* __restrict__ G0, const T* __restrict__ G1, const T* __restrict__ G2,
-    const T* __restrict__ G3, T* __restrict__ g_means, T* __restrict__ g_conics, T* __restrict__ g_values, Resid<T> rz) {
+    const T* __restrict__ G3, T* __restrict__ g_means, T* __restrict__ g_conics, T* __restrict__ g_values, Resid<T> rz,
+    int slice) {      // points per slice: 64, or 32 where 64 would leave most of the chip without a workgroup
     using L = BwdLayout<D, C>;
     constexpr int NF = Sym<D>::NF;
     constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;
@@ -280,8 +285,8 @@ __global__ __launch_bounds__(256) void dense_backward_staged_kernel(
     for (int k = 0; k < NF; ++k) con[k] = conics[nn * NF + k];
 #pragma unroll
     for (int k = 0; k < C; ++k) v[k] = values[nn * C + k];
-    const int64_t m0 = (int64_t)blockIdx.y * 64;
-    const int cnt = (int)(M - m0 < 64 ? M - m0 : 64);
+    const int64_t m0 = (int64_t)blockIdx.y * slice;
+    const int cnt = (int)(M - m0 < slice ? M - m0 : slice);
     if ((int)threadIdx.x < cnt) {
         const int64_t m = m0 + threadIdx.x;
         Pt p;
@@ -384,10 +389,12 @@ static int launch_dense_backward(const SampleArgs& a, hipStream_t stream) {
     // few points: 64-point slices staged in LDS, 256 Gaussians per workgroup (dense_backward_staged_kernel)
     if (a.M <= 16384 && (a.M + 63) / 64 <= 65535) {
         zero_grads();
-        hipLaunchKernelGGL((dense_backward_staged_kernel<T, D, C, MASK>), dim3((unsigned)((a.N + 255) / 256), (unsigned)((a.M + 63) / 64)),
+        const int64_t gx = (a.N + 255) / 256;
+        const int slice = gx * ((a.M + 63) / 64) < 512 ? 32 : 64;      // N = 1 600, 1 024 points: 112 workgroups of 64-point slices
+        hipLaunchKernelGGL((dense_backward_staged_kernel<T, D, C, MASK>), dim3((unsigned)gx, (unsigned)((a.M + slice - 1) / slice)),
                            dim3(256), 0, stream, a.N, a.M, (const T*)a.means, (const T*)a.conics, (const T*)a.values,
                            (const T*)a.samples, (const T*)a.gout[0], (const T*)a.gout[1], (const T*)a.gout[2], (const T*)a.gout[3],
-                           gm, gc, gv, Resid<T>{(T)a.resid[0], {(T)a.resid[1], (T)a.resid[2]}, (T)a.resid[3], nullptr});
+                           gm, gc, gv, Resid<T>{(T)a.resid[0], {(T)a.resid[1], (T)a.resid[2]}, (T)a.resid[3], nullptr}, slice);
         return launch_status();
     }
     // split the point range over gridDim.y so that ~2048 workgroups exist; each wave should
