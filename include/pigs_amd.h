@@ -125,7 +125,7 @@ size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsuppor
  * per-workgroup LDS ranking inside 256 coarse bins, a scan of the (bin, workgroup) counts, a scatter into bin
  * segments and a per-bin LDS sort; right for points in no order (torch.rand collocation points, main_pn.py:103),
  * which otherwise pay one global atomic and one 12-byte scattered write each.  The host cannot see which it
- * has without a synchronisation, so the library remembers, per device and M: every build of M >= 32 768
+ * has without a synchronisation, so the library remembers, per device and M: every build of M >= 131 072
  * points leaves {runs, points} of a sample of its waves in the workspace, copied to pinned memory on `stream`
  * behind the build (nobody waits); the next build of the same M takes the path the last completed copy
  * recommends (more than 0.55 runs per point: coarse bins).  Captured builds neither ask nor copy.
@@ -134,7 +134,8 @@ size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c);   /* 0 = unsuppor
  * The same memory decides how pigs_plan_forward / pigs_plan_backward move the outputs / incoming gradients of
  * c = 1, orders (0, 1, 2) or (0, 1, trace) launches: directly through the points' original indices (lattices:
  * runs of consecutive indices), or -- points in no order -- through one 32-byte record per point in the plan
- * workspace and a streaming launch that deals the records out / gathers them (PIGS_STAGE=0|1 overrules). */
+ * workspace and a streaming launch that deals the records out / gathers them (from 524 288 points, where it
+ * starts to pay; PIGS_STAGE=0|1 overrules). */
 int pigs_samples_build(void* samples_ws, size_t samples_ws_bytes, int64_t M, const void* samples, void* stream);
 /* what the library currently remembers for builds of M points on the current device: 1 = coarse bins,
  * 0 = one pass, -1 = nothing yet (introspection for tools and tests) */

@@ -2272,7 +2272,14 @@ static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, c
 // neither asks nor copies (it keeps the mode of the moment).  PIGS_SAMPLES_ORDER = ordered | unordered in the
 // environment, or the PIGS_BUILD_POINTS_* flags, overrule the memory; the result is the same either way
 // (order inside a fine cell aside), only the time differs.
-constexpr int64_t COARSE_MIN_POINTS = 1 << 15;      // below: the build is a handful of launch latencies either way
+// Where the two mechanisms start to pay, measured on uniform random points with one Gaussian per 16 points (one box,
+// cold step / forward launches / backward launches, us): 256^2 points: one-pass 49.1 / 18.7 / 19.1, coarse-bin 51.1,
+// staged 23.0 / 22.4; 384^2: 61.1 vs 58.9 cold, staged forward 20.8 vs 14.3; 512^2: 70.8 vs 66.9 cold, staged
+// 32.2 / 45.2 vs 30.4 / 39.5; 1024^2: 162 vs 122 cold, staged 49 / 104 vs 57 / 110.  Below ~100 k points the extra
+// launch of the coarse-bin build costs more than the atomics it saves, and the staging launch more than the
+// scattered sectors up to ~500 k.
+constexpr int64_t COARSE_MIN_POINTS = 1 << 17;
+constexpr int64_t STAGE_MIN_POINTS = 1 << 19;
 struct OrderHint {
     int device = -1;
     int64_t M = 0;
@@ -2370,7 +2377,7 @@ static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t st
 // collocation points) never comes back to samples_take_coarse -- unless the stream is being captured.
 static bool points_unordered(int64_t M, hipStream_t stream) {
     if (const char* e = getenv("PIGS_STAGE")) return e[0] == '1';          // tests / A-B runs: staging on or off whatever the memory and the size
-    if (M < COARSE_MIN_POINTS) return false;
+    if (M < STAGE_MIN_POINTS) return false;
     if (const char* e = getenv("PIGS_SAMPLES_ORDER")) return !strcmp(e, "unordered");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }

@@ -100,14 +100,14 @@ def test_coarse_bin_build_at_bench_size_equals_the_one_pass_build(Sampler):
 
 
 def test_library_remembers_how_a_point_set_of_a_size_arrived(Sampler, hip_lib):
-    """No environment override: builds of M >= 32 768 points leave their run statistic behind (asked for after
+    """No environment override: builds of M >= 131 072 points leave their run statistic behind (asked for after
     the first two builds of a size and after every 16th), and later builds of that M take the recommended
     path -- random points switch to coarse bins, a lattice of the same size switches back.  Results hold
     on either path."""
-    M = 300 * 300
+    M = 400 * 400
     rng = np.random.default_rng(9)
     means, con, values = random_gaussians(rng, 2000, 1, log_sigma_mean=-3.3, log_sigma_std=0.4)
-    g = np.linspace(-1, 1, 300)
+    g = np.linspace(-1, 1, 400)
     gx, gy = np.meshgrid(g, g, indexing="xy")
     grid = np.stack((gx, gy), -1).reshape(-1, 2)
     rnd = rng.uniform(-1, 1, (M, 2))
@@ -164,9 +164,9 @@ def test_the_memory_does_not_run_out_of_slots(Sampler, hip_lib):
     with forced_order(None), torch.no_grad():
         s = Sampler(False, backend="binned", reuse_samples=False)
         for k in range(24):                              # more one-off sizes than there are slots
-            s.preprocess(t[0], t[1], None, t[2], dev32(rng.uniform(-1, 1, (40000 + 64 * k, 2))))
+            s.preprocess(t[0], t[1], None, t[2], dev32(rng.uniform(-1, 1, (140000 + 64 * k, 2))))
         torch.cuda.synchronize()
-        M = 51111
+        M = 151111
         p = dev32(rng.uniform(-1, 1, (M, 2)))
         for _ in range(36):
             s.preprocess(t[0], t[1], None, t[2], p)

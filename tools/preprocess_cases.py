@@ -9,19 +9,21 @@ from pigs_amd import synthetic
 from diff_gaussian_sampling import GaussianSampler
 
 case, kappa = sys.argv[1], float(sys.argv[2])
-gs = synthetic.lattice_gaussians(256, 256, kappa, seed=1)
+LAT = int(os.environ.get("PIGS_CASE_LAT", "256"))          # Gaussians: LAT x LAT lattice (C3: 256)
+RES = int(os.environ.get("PIGS_CASE_RES", "1024"))         # points: RES x RES (C3: 1024)
+gs = synthetic.lattice_gaussians(LAT, LAT, kappa, seed=1)
 t = {k: v.float().cuda() for k, v in gs.items()}
 g = torch.Generator().manual_seed(3)
 if case == "grid":
-    pts = synthetic.grid_samples(1024).float()
+    pts = synthetic.grid_samples(RES).float()
 elif case == "random":
-    pts = torch.rand((1 << 20, 2), generator=g) * 2 - 1
+    pts = torch.rand((RES * RES, 2), generator=g) * 2 - 1
 elif case == "shuffled":
-    pts = synthetic.grid_samples(1024).float()
+    pts = synthetic.grid_samples(RES).float()
     pts = pts[torch.randperm(pts.shape[0], generator=g)]
 elif case.startswith("clustered"):       # clustered, or clustered:<sigma> (test_no_mlp.py:86 draws randn / 2, clamped)
     sigma = float(case.split(":")[1]) if ":" in case else 0.15
-    pts = (torch.randn((1 << 20, 2), generator=g) * sigma).clamp(-1, 1)
+    pts = (torch.randn((RES * RES, 2), generator=g) * sigma).clamp(-1, 1)
 else:
     raise SystemExit("unknown case")
 pts = pts.cuda()
