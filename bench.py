@@ -263,6 +263,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # build (or wait for local rank 0's build) BEFORE anything touches the GPU: compiling forks hipcc / g++,
+    # and a compiler exec chain behind a GPU-initialised or profiled process is forbidden on the GPU pool
+    import importlib
+    importlib.import_module("pigs_amd.build").ensure_built(wait_for_rank0=local_rank != 0)
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -279,11 +283,6 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    import pigs_amd
-    if local_rank == 0:
-        pigs_amd.build()                 # no-op when the in-tree library matches the sources
-    if dist is not None:
-        dist.barrier()                   # the other ranks wait for the library instead of rebuilding it
     from diff_gaussian_sampling import GaussianSampler
     from pigs_amd import synthetic, sampler as S
 

@@ -149,6 +149,37 @@ def build_all(force=False, verbose=False):
     return LIB
 
 
+def under_profiler():
+    """True inside a rocprofv3 run: the profiler's preloaded tool library initialises the GPU before the
+    program starts, and everything the process forks inherits the preload."""
+    env = os.environ
+    return ("rocprof" in env.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in env
+            or "ROCPROFILER_REGISTER_FORCE_LOAD" in env or any(k.startswith("ROCPROF_") for k in env))
+
+
+def ensure_built(wait_for_rank0=False):
+    """What an entry point (bench.py, tools/prof_*.py) calls as its FIRST statement, before anything touches
+    the GPU: building forks hipcc / g++, whose wrappers exec the compiler proper, and an exec chain behind a
+    GPU-initialised (or profiled) process is what the GPU pool forbids.  Inside a rocprofv3 run nothing is
+    ever built: stale libraries end the run with the command that fixes it.  ``wait_for_rank0``: a rank other
+    than local rank 0 waits for rank 0's build instead of racing it."""
+    stale = needs_build() or host_needs_build()
+    if not stale:
+        return LIB
+    if under_profiler():
+        sys.exit("pigs_amd: the in-tree libraries are stale and this is a profiler run -- run "
+                 "`python -m pigs_amd.build` first (nothing is compiled behind rocprofv3)")
+    if wait_for_rank0:
+        import time
+        t0 = time.time()
+        while needs_build() or host_needs_build():
+            if time.time() - t0 > 900:
+                sys.exit("pigs_amd: gave up waiting for local rank 0 to build the libraries")
+            time.sleep(0.5)
+        return LIB
+    return build_all()
+
+
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -18,6 +18,7 @@
 #include <torch/extension.h>
 #include <torch/csrc/autograd/function.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/core/DeviceGuard.h>
 #include <hip/hip_runtime_api.h>
 
@@ -162,12 +163,21 @@ struct Plan {
     PlanPool::Key key;
     hipStream_t build_stream = nullptr;
     bool other_stream_used = false;      // a launch on another stream read the workspace: stream order no longer covers a reuse
+    bool recorded_only = false;          // built inside a hipGraph capture: it has run only if (and when) that graph was replayed
 
     ~Plan() {
         if (pool && !other_stream_used && workspace.defined()) pool->give(key, std::move(workspace));
     }
     void note_stream(hipStream_t s) {
-        if (s != build_stream) other_stream_used = true;
+        if (s == build_stream) return;
+        other_stream_used = true;
+        // the caching allocator hands a freed block out again in the order of the stream it was allocated on:
+        // kernels still queued on THIS stream must be known to it (both workspaces; idempotent per stream)
+        c10::hip::HIPStream hs = c10::hip::getCurrentHIPStream(workspace.device().index());      // the caller's: what every call site passes
+        if (hs.stream() != s) hs = c10::hip::getStreamFromExternal(s, workspace.device().index());
+        c10::hip::HIPCachingAllocator::recordStream(workspace.storage().data_ptr(), hs);
+        if (samples && samples->workspace.defined())
+            c10::hip::HIPCachingAllocator::recordStream(samples->workspace.storage().data_ptr(), hs);
     }
 };
 
@@ -196,7 +206,11 @@ std::shared_ptr<Plan> build_plan(const at::Tensor& means, const at::Tensor& valu
                           flags, plan->N, plan->M, plan->c, q_max, plan->q_max_backward, ptr(means), ptr(conics), ptr(values), ptr(samples),
                           stream),
           "pigs_plan_build");
-    sp->built = true;
+    // a build that was only RECORDED into a hipGraph capture has not run: it never marks the samples half built
+    // (an eager call that finds `built` set skips PIGS_BUILD_SAMPLES and would sample a workspace that never
+    // executed); a SamplePlan that WAS built eagerly stays built whatever is recorded on top of it
+    plan->recorded_only = capturing(stream);
+    sp->built = sp->built || !plan->recorded_only;
     plan->pool = pool_or_null;      // only a workspace whose build was launched completely goes back
     return plan;
 }
@@ -690,7 +704,17 @@ struct Core {
     }
 
     std::shared_ptr<Plan> plan_for(int mask) {
-        if (!plan || !(mask & 8) || q_max3 == q_max) return plan;
+        if (!plan) return plan;
+        const bool cap = capturing(current_stream(means));
+        // An eager call behind a capture (no preprocess in between) must not sample what the capture only RECORDED:
+        // the plan is rebuilt eagerly, on a samples half of its own (the recorded one belongs to the graph, whose
+        // replays re-sort it).
+        if (plan->recorded_only && !cap) {
+            plan = make_plan(q_max, nullptr);
+            plan3.reset();
+        }
+        if (!(mask & 8) || q_max3 == q_max) return plan;
+        if (plan3 && plan3->recorded_only && !cap) plan3.reset();
         if (!plan3) plan3 = make_plan(q_max3, plan->samples);      // same points: the sorted samples are shared
         return plan3;
     }
@@ -741,7 +765,7 @@ struct Core {
 
     at::Tensor residual(const std::array<double, 4>& coeffs, const c10::optional<at::Tensor>& target) {
         require_inputs();
-        return residual_apply(means, values, conics, samples, coeffs, target, debug, plan);
+        return residual_apply(means, values, conics, samples, coeffs, target, debug, plan_for(0));
     }
 
     void preprocess_aggregate(int64_t cap) {
@@ -821,6 +845,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("q_max", &Plan::q_max)
         .def_readonly("q_max_backward", &Plan::q_max_backward)
         .def_readonly("other_stream_used", &Plan::other_stream_used)
+        .def_readonly("recorded_only", &Plan::recorded_only)
         .def("scan_took_slow_path", [](const Plan& p) {
             return error_flag(p.samples->workspace, pigs_samples_error_offset()) != 0 ||
                    error_flag(p.workspace, pigs_plan_error_offset()) != 0;

@@ -134,7 +134,9 @@ class _PlanPool:
         self.free = {}             # key -> [workspace, ...]; dict order = least recently given first
         # plans die wherever their last reference is dropped -- the autograd engine's worker threads and
         # the garbage collector included -- while the main thread may be inside take()
-        self.lock = threading.Lock()
+        # (re-entrant: give() allocates while it holds the lock, a collector pass triggered there can finalise a
+        # Plan in a reference cycle, whose __del__ comes back into give() on the same thread)
+        self.lock = threading.RLock()
 
     def take(self, key):
         with self.lock:
@@ -166,7 +168,7 @@ class Plan:
     pending backward."""
 
     __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "q_max_backward", "_pool", "_pool_key",
-                 "build_stream", "other_stream_used")
+                 "build_stream", "other_stream_used", "recorded_only")
 
     BUILD_SAMPLES, WS_CLEAN = 1, 2      # pigs_amd.h: PIGS_BUILD_SAMPLES, PIGS_BUILD_PLAN_WS_CLEAN
 
@@ -177,6 +179,7 @@ class Plan:
         self.q_max_backward = max(self.q_max, float(q_max_backward if q_max_backward is not None else q_max))
         self._pool = None
         self.other_stream_used = False
+        self.recorded_only = bool(recorded_only)      # built inside a capture: has run only if that graph was replayed
         key = (self.N, self.M, self.c)
         nbytes = _WORKSPACE_BYTES.get(key)
         if nbytes is None:
@@ -201,15 +204,22 @@ class Plan:
                                      flags, self.N, self.M, self.c, self.q_max, self.q_max_backward,
                                      _ptr(means), _ptr(conics), _ptr(values), _ptr(samples), stream)
         _lib.check(rc, "pigs_plan_build")
-        # a build that was only RECORDED into a hipGraph has not run: nothing eager may rely on it
-        sample_plan.built = not recorded_only
+        # a build that was only RECORDED into a hipGraph has not run: nothing eager may rely on it -- and a
+        # SamplePlan that WAS built eagerly stays built whatever is recorded on top of it (lowering the flag
+        # would make the next eager preprocess re-sort a workspace older plans still hold tile lists for)
+        sample_plan.built = sample_plan.built or not recorded_only
         self._pool = pool            # only a workspace whose build was launched completely goes back
 
     def note_stream(self, stream_value):
         """A launch on another stream than the build's reads the workspace: stream order no longer
-        covers its reuse, so it does not go back to the pool."""
+        covers its reuse, so it does not go back to the pool -- and the caching allocator, which hands a freed
+        block out again in the order of its allocation stream, is told about the other stream."""
         if stream_value != self.build_stream:
             self.other_stream_used = True
+            st = torch.cuda.current_stream(self.workspace.device)
+            if st.cuda_stream == stream_value:
+                self.workspace.record_stream(st)
+                self.samples.workspace.record_stream(st)
 
     def __del__(self):
         try:
@@ -409,6 +419,13 @@ def _load_native_host():
     """The native host extension (pigs_amd/_pigs_host.so, csrc_host/pigs_host.cpp); there is no silent
     fallback to the ctypes host: a missing extension raises."""
     _lib.load()
+    variant = os.environ.get("PIGS_AMD_LIB")
+    if variant and os.path.realpath(variant) != os.path.realpath(os.path.join(_lib.HERE, "libpigs_amd.so")):
+        # _pigs_host.so resolves libpigs_amd.so through its $ORIGIN rpath: the launches would run the in-tree
+        # library while the ctypes calls ran the variant -- two instances with separate state, an A/B run
+        # timing the wrong kernels without noticing
+        raise ImportError(f"PIGS_AMD_LIB={variant} selects a variant library, which only the ctypes host can drive: "
+                          "construct GaussianSampler(..., host='ctypes') or set PIGS_AMD_HOST=ctypes")
     try:
         from . import _pigs_host
     except ImportError as e:
@@ -647,8 +664,19 @@ class GaussianSampler:
 
     def _plan_for(self, mask):
         """The plan a launch with this order mask runs on: third derivatives get the wider cut-off."""
-        if self._st_plan is None or not mask & 8 or self.q_max_order3 == self.q_max:
+        if self._st_plan is None:
+            return None
+        capturing = torch.cuda.is_current_stream_capturing()
+        # an eager call behind a capture (no preprocess in between) must not sample what the capture only
+        # RECORDED: the plan is rebuilt eagerly, on a samples half of its own (the recorded one belongs to the
+        # graph, whose replays re-sort it)
+        if self._st_plan.recorded_only and not capturing:
+            self._st_plan = self._build_plan(self.q_max)
+            self._st_plan3 = None
+        if not mask & 8 or self.q_max_order3 == self.q_max:
             return self._st_plan
+        if self._st_plan3 is not None and self._st_plan3.recorded_only and not capturing:
+            self._st_plan3 = None
         if self._st_plan3 is None:
             self._st_plan3 = self._build_plan(self.q_max_order3, self._st_plan.samples)     # same points: the sorted samples are shared
         return self._st_plan3
@@ -719,7 +747,7 @@ class GaussianSampler:
             target = target.reshape(M, c)
         if self._core is not None:
             return self._core.residual(coeffs, target)
-        return _ResidualFunction.apply(means, values, conics, samples, target, coeffs, self.debug, self._plan)
+        return _ResidualFunction.apply(means, values, conics, samples, target, coeffs, self.debug, self._plan_for(0))
 
     def sample_gaussians(self):
         """u [M, c]"""

@@ -181,6 +181,50 @@ def test_capture_leaves_no_unbuilt_sample_plan_behind(hip_lib, host):
     assert rel(u, exp[0]) < 1e-5
 
 
+@pytest.mark.parametrize("host", HOSTS)
+def test_eager_calls_behind_a_capture_do_not_sample_a_recorded_plan(hip_lib, host):
+    """a capture records preprocess + sample; an EAGER sample_*() afterwards, with no new
+    preprocess, must not run on what was only recorded (a samples workspace that never executed) -- the
+    order-3 call builds its second plan, the order-1 call samples the first one: both against the oracle.
+    And a SamplePlan that was built eagerly stays built when a capture records another plan on top of it."""
+    from diff_gaussian_sampling import GaussianSampler
+    dev = torch.device("cuda")
+    t, pts = case(16, 48)
+    sampler = GaussianSampler(False, backend="binned", fuse="none", host=host)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    warm = synthetic.grid_samples(40).float().to(dev)
+    with torch.cuda.stream(side), torch.no_grad():
+        sampler.preprocess(t["means"], t["values"], None, t["conics"], warm)
+        sampler.sample_gaussians()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side), torch.no_grad():
+        sampler.preprocess(t["means"], t["values"], None, t["conics"], pts)
+        sampler.sample_gaussians()
+    assert sampler._plan.recorded_only and not sampler._plan.samples.built
+    with torch.no_grad():                        # never replayed: nothing the capture recorded has run
+        d3 = sampler.sample_gaussians_third_derivative()
+        d1 = sampler.sample_gaussians_derivative()
+    assert not sampler._plan.recorded_only and sampler._plan.samples.built
+    args = [t[k].detach().cpu().double().numpy() for k in ("means", "conics", "values")]
+    exp = c_oracle.forward(*args, pts.cpu().double().numpy(), orders=(1, 3))
+    assert rel(d1, exp[1]) < 1e-5 and rel(d3, exp[3]) < 1e-5
+    # the mirror: an eagerly built SamplePlan keeps `built` when a capture builds the order-3 plan on it
+    sp = sampler._plan.samples
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        torch.cuda.current_stream().wait_stream(torch.cuda.default_stream())
+    with torch.no_grad():
+        sampler.preprocess(t["means"], t["values"], None, t["conics"], pts)      # eager, remembered points
+        sp = sampler._plan.samples
+        assert sp.built
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph2, stream=side), torch.no_grad():
+        sampler.sample_gaussians_third_derivative()                              # records plan3 on the built samples
+    assert sp.built
+
+
 def test_plan_used_on_another_stream_is_not_recycled(hip_lib):
     from diff_gaussian_sampling import GaussianSampler
     t, pts = case(16, 48)

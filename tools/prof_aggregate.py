@@ -3,6 +3,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import importlib
+importlib.import_module("pigs_amd.build").ensure_built()      # before anything touches the GPU; never builds behind rocprofv3
 from pigs_amd import synthetic
 from diff_gaussian_sampling import GaussianSampler
 

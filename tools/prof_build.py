@@ -4,6 +4,8 @@ Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import importlib
+importlib.import_module("pigs_amd.build").ensure_built()      # before anything touches the GPU; never builds behind rocprofv3
 from pigs_amd import synthetic
 from pigs_amd.sampler import GaussianSampler
 

@@ -47,8 +47,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--stats", action="store_true")
     a = ap.parse_args()
-    import pigs_amd
-    pigs_amd.build()
+    import importlib
+    importlib.import_module("pigs_amd.build").ensure_built()      # before anything touches the GPU; never builds behind rocprofv3
     from diff_gaussian_sampling import GaussianSampler
     from pigs_amd import synthetic, sampler as S
     dev = torch.device("cuda", 0)
