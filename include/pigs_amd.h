@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 6
+#define PIGS_ABI_VERSION 7
 
 enum pigs_status {
     PIGS_OK = 0,
@@ -163,6 +163,17 @@ int pigs_samples_order_hint(int64_t M);
 #define PIGS_BUILD_DEBUG_NO_LOOKBACK 4
 #define PIGS_BUILD_POINTS_ORDERED 8
 #define PIGS_BUILD_POINTS_UNORDERED 16
+/* ABI 7.  PIGS_BUILD_DEFER_LISTS: the build stops in front of its last launch, the tile lists; the FIRST
+ * pigs_plan_forward / pigs_plan_backward / pigs_residual_* call on this plan workspace builds them -- a forward
+ * (orders 0..2, orders 0, 1 + trace, order 0, the residual; c = 1, and orders 0..2 for c = 2) in the SAME launch
+ * as its own evaluation: a wave builds the lists of its four tiles and samples them at once, so the latency-bound
+ * list build hides behind the arithmetic of the other waves and one kernel boundary goes away (the reference's
+ * pattern: preprocess, then sample_*(), model_pn.py:768-772).  The lists are written out as ever; every further
+ * call reads them.  The library remembers which workspaces are waiting by their address (every build into a
+ * workspace sets or clears the mark, the first sampling call clears it); the first sampling call must be stream
+ * ordered behind the build, like any use of the plan.  PIGS_NO_FUSED_FIRST in the environment keeps the list
+ * build in a launch of its own (A/B runs). */
+#define PIGS_BUILD_DEFER_LISTS 32
 int pigs_plan_build(void* workspace, size_t workspace_bytes, void* samples_ws, size_t samples_ws_bytes,
                     int flags, int64_t N, int64_t M, int c, float q_max, float q_max_backward,
                     const void* means, const void* conics, const void* values, const void* samples, void* stream);
@@ -204,6 +215,17 @@ int pigs_residual_backward(int dtype, int d, int c, int64_t N, int64_t M,
  * (ABI <= 5: the scan gave up instead and this word meant "workspace invalid".) */
 size_t pigs_samples_error_offset(void);
 size_t pigs_plan_error_offset(void);
+
+/* ABI 7.  Byte offset, inside a samples workspace, of two uint32 {rf, rs} that a samples build leaves behind:
+ * non-zero when the points were taken in INDEX-TILED order -- they arrived as an rf x rs lattice in row order
+ * (rf points along the fastest axis; both multiples of 8: meshgrid(indexing="xy").reshape(-1, 2),
+ * test_gaussian_sampling.py:43-46, main_pn.py:317-324), so a point's tile (an 8 x 8 index patch) and group (4 x 4)
+ * are index arithmetic and the build neither keys, counts, scans nor scatters the points (its first launch writes
+ * them in tile order) -- and {0, 0} when they were sorted into cells.  The decision is the build's own, on the
+ * device (the first descent of a coordinate gives rf; every index tile must be at most twice as wide and as tall
+ * as its share of the bounding box); results never depend on it, PIGS_LATTICE=0 in the environment switches it
+ * off.  Introspection for tools and tests. */
+size_t pigs_samples_lattice_offset(void);
 
 /* Introspection for tools and tests (never needed to use a plan): where the tile lists sit inside a
  * plan workspace.  info[0] = tiles, info[1] = entries per list slab, info[2] = byte offset of the

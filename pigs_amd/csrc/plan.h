@@ -119,7 +119,44 @@ struct SampleParams {
     // one-pass build, and the next build of a point set of this size takes the coarse-bin path
     // (SAMPLES_COARSE_BINS below; the library reads this pair back without synchronising, plan.hip).
     uint32_t order_stat[2];
+    // INDEX-TILED ("lattice") order (round 4).  A point set that arrives as an rf x rs lattice in row order (rf
+    // points along the fast axis, both multiples of 8: meshgrid(indexing="xy").reshape(-1, 2),
+    // test_gaussian_sampling.py:43-46, main_pn.py:317-324) needs no sort: its tile of a point is index
+    // arithmetic (lattice_tile_xy / lattice_index below: tile = an 8 x 8 index patch, group = a 4 x 4 patch,
+    // tiles in serpentine pair-rows so that 4 consecutive tiles from a multiple of 4 are a compact block), and the
+    // first build launch writes `spts` in that order itself -- no cell keys, no counters, no scan, no scatter of the
+    // points.  Correctness never depends on the points BEING a lattice (the lists are built from the groups' real
+    // bounding boxes): the detection (first descent of a coordinate = the row length; every index tile no wider
+    // than twice its share of the bounding box) only decides which order is compact.
+    // lat_cand: {candidate rf, fast axis (0: x, 1: y)} from the first launch; lat: {rf, rs} when the points are
+    // index-tiled, {0, 0} when they were sorted into cells.
+    uint32_t lat_cand[2];
+    uint32_t lat[2];
 };
+
+// ---- index-tiled order: position in `spts` <-> index in the caller's array -------------------
+// tile -> (tx, ty) in a grid of ntx x nty tiles of 8 x 8 points: pair-rows of tiles taken alternately left to right
+// and right to left, inside a pair-row column by column (so tiles 4j .. 4j+3 are the 2 x 2 block of tile columns
+// 2j, 2j+1 -- or, where an odd ntx makes a block straddle two pair-rows, a 1 x 4 column at the turning edge); an
+// odd nty leaves a single last row that continues the serpentine.
+__host__ __device__ inline void lattice_tile_xy(uint32_t tile, uint32_t ntx, uint32_t nty, uint32_t& tx, uint32_t& ty) {
+    const uint32_t pair = 2u * ntx, full = (nty >> 1) * pair;
+    if (tile < full) {
+        const uint32_t pr = tile / pair, k = tile - pr * pair, txs = k >> 1;
+        ty = 2u * pr + (k & 1u);
+        tx = (pr & 1u) ? ntx - 1u - txs : txs;
+    } else {
+        const uint32_t k = tile - full;
+        ty = nty - 1u;
+        tx = ((nty >> 1) & 1u) ? ntx - 1u - k : k;
+    }
+}
+// lane -> the point's index in the caller's array: group g = lane / 16 is the 4 x 4 patch (g & 1, g >> 1) of the tile
+__host__ __device__ inline uint32_t lattice_index(uint32_t tx, uint32_t ty, uint32_t lane, uint32_t rf) {
+    const uint32_t g = lane >> 4, i = lane & 15u;
+    const uint32_t col = tx * 8u + (g & 1u) * 4u + (i & 3u), row = ty * 8u + (g >> 1) * 4u + (i >> 2);
+    return row * rf + col;
+}
 
 // Written once per plan build (first bytes of the plan workspace), read by the sampling kernels.
 struct PlanParams {
@@ -166,7 +203,7 @@ struct SamplesLayout {
     uint32_t h_chunk;          // points per histogram workgroup (a multiple of 2048)
     uint32_t h_wgs;            // histogram workgroups (a multiple of 4: the matrix is whole scan blocks)
     uint32_t h_scan_blocks;    // = SAMPLES_COARSE_BINS * h_wgs / PLAN_SCAN_BLOCK
-    size_t off_params, off_boxes, off_counts, off_agg, off_starts, off_skey, off_spts, off_hist, off_hagg, off_hstarts,
+    size_t off_params, off_boxes, off_lat, off_counts, off_agg, off_starts, off_skey, off_spts, off_hist, off_hagg, off_hstarts,
         off_tmp, total_bytes;
 };
 
@@ -183,6 +220,7 @@ inline SamplesLayout make_samples_layout(int64_t M) {
     size_t o = 0;
     p.off_params = o;   o = align_up(o + sizeof(SampleParams), 256);
     p.off_boxes = o;    o = align_up(o + sizeof(float4) * PLAN_BBOX_BLOCKS, 256);
+    p.off_lat = o;      o = align_up(o + sizeof(float2) * PLAN_BBOX_BLOCKS, 256);   // per-workgroup {widest, tallest} index tile
     // counters and the scan's per-workgroup aggregates are adjacent: zeroed together
     p.off_counts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
     p.off_agg = o;      o = align_up(o + sizeof(uint64_t) * (size_t)p.scan_blocks, 256);

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 #ifndef PIGS_FWD_WAVES
 #define PIGS_FWD_WAVES 8      // waves per SIMD the forward kernel's register budget is held to
@@ -64,6 +65,8 @@ struct BuildArgs {
     // samples side
     SampleParams* sparams;
     float4* sboxes;       // [PLAN_BBOX_BLOCKS] per-workgroup partial boxes {min x, min y, max x, max y}
+    float2* slat;         // [PLAN_BBOX_BLOCKS] per-workgroup {widest, tallest} index tile (index-tiled order, plan.h)
+    int no_lattice;       // PIGS_LATTICE=0: never index-tiled (tests, A/B)
     uint32_t* scounts;    // [s_scan_blocks * PLAN_SCAN_BLOCK] fine-cell counters, followed by the scan aggregates
     unsigned long long* sagg;
     uint32_t* sstarts;
@@ -99,23 +102,66 @@ struct BuildArgs {
     // which halves this build covers
     int do_samples, do_plan;
     int no_lookback;      // test hook: the scan's workgroups never publish; every look-back recomputes
+    int zero_gacc;        // the backward's scratch is not known to be zero (a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN)
 };
 
 __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
     uint4* p4 = (uint4*)p;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < words / 4; i += gridDim.x * 256) p4[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words / 4; i += gridDim.x * blockDim.x) p4[i] = make_uint4(0, 0, 0, 0);
 }
 
-// Launch 1 of a samples build (PLAN_BBOX_BLOCKS workgroups): zero the cell counters (of the plan
-// too, when one is built alongside); per-workgroup bounding box of the sample points, 8 float4
-// loads (16 points) in flight per thread, written as a plain partial.
-__global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
-    __shared__ float sh[4][4];
+// Bounding boxes with the DPP modifier fused into the min / max (hipcc emits v_mov_dpp + a
+// canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  The four
+// reductions are independent chains and are interleaved step by step, so the two wait states a
+// DPP read needs after the VALU write of its source are filled by the other three chains: one
+// s_nop at the head instead of one per step (an s_nop costs an issue slot like a VALU
+// instruction).  row_box_dpp leaves in every lane the box of the lane's own 16-lane row;
+// wave_box_dpp continues from there to the box of the wave, broadcast from lane 63.
+#define PIGS_BOX_STEP(MOD)                                \
+    "v_min_f32_dpp %0, %0, %0 " MOD " bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %1, %1, %1 " MOD " bank_mask:0xf\n\t" \
+    "v_min_f32_dpp %2, %2, %2 " MOD " bank_mask:0xf\n\t" \
+    "v_max_f32_dpp %3, %3, %3 " MOD " bank_mask:0xf\n\t"
+__device__ __forceinline__ void row_box_dpp(float& x0, float& x1, float& y0, float& y1) {
+    asm volatile("s_nop 1\n\t"
+                 PIGS_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
+                 PIGS_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
+                 PIGS_BOX_STEP("row_half_mirror row_mask:0xf")
+                 PIGS_BOX_STEP("row_mirror row_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+}
+__device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, float& y0, float& y1) {
+    asm volatile("s_nop 1\n\t"
+                 PIGS_BOX_STEP("row_bcast:15 row_mask:0xa")
+                 PIGS_BOX_STEP("row_bcast:31 row_mask:0xc")
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+    x0 = readlane_f(x0, 63); x1 = readlane_f(x1, 63); y0 = readlane_f(y0, 63); y1 = readlane_f(y1, 63);
+}
+
+// Launch 1 of a samples build (PLAN_BBOX_BLOCKS workgroups of 1 024 threads): zero the cell counters (of the
+// plan too, when one is built alongside); per-workgroup bounding box of the sample points, written as a plain
+// partial.  And the INDEX-TILED order (plan.h, SampleParams::lat): every workgroup finds the first index at which
+// a coordinate descends -- the row length rf of a lattice in row order (a search of the first 2 049 points, of
+// 16 385 when those hold none; all workgroups read the same few KB) -- and, when rf and M / rf are multiples of 8,
+// takes the points tile by tile instead of linearly: the wave writes the tile's 64 points to `spts` in tile order
+// (the sort's whole output for such a point set) and keeps the widest / tallest tile it met, from which the next
+// launch decides whether the index tiles are compact (and the sort is skipped) or the candidate was a coincidence
+// (and the sort overwrites `spts`).
+constexpr uint32_t BBOX_THREADS = 1024;
+constexpr uint32_t LAT_SEARCH0 = 2048, LAT_SEARCH1 = 16384;
+__global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
+    __shared__ float sh[16][6];
+    __shared__ uint32_t shk[16];
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     zero_words(a.szero, a.s_zero_words);
-    if (blockIdx.x == 0 && threadIdx.x < 2) a.sparams->order_stat[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && tid < 2) a.sparams->order_stat[tid] = 0u;
     if (a.do_plan) {
         zero_words(a.counts, a.zero_words);
-        if (blockIdx.x == 0 && threadIdx.x < PLAN_BAR_WORDS) a.params->bar[threadIdx.x] = 0u;
+        if (a.zero_gacc) zero_words((uint32_t*)a.gacc, 8u * a.N);
+        if (blockIdx.x == 0 && tid < PLAN_BAR_WORDS) a.params->bar[tid] = 0u;
     }
     const float INF = __builtin_huge_valf();
     float x0 = INF, y0 = INF, x1 = -INF, y1 = -INF;
@@ -123,33 +169,112 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
         if (fabsf(x) < INF) { x0 = fminf(x0, x); x1 = fmaxf(x1, x); }
         if (fabsf(y) < INF) { y0 = fminf(y0, y); y1 = fmaxf(y1, y); }
     };
-    const float4* pts2 = (const float4*)a.samples;
     const float2* pts = (const float2*)a.samples;
     const uint32_t n = a.M;
-    const uint32_t npair = n / 2;                 // float4 = two points
-    const uint32_t stride = gridDim.x * 256;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npair; i += 8 * stride) {
-        float4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t j = i + k * stride;
-            v[k] = pts2[j < npair ? j : i];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
+    // ---- the candidate row length.  The fast axis is the one along which the first two points differ most, its
+    // direction the sign of that step; a row ends where the fast coordinate steps the other way (a jittered lattice
+    // keeps its rows as long as the jitter stays below half a step).  key = that first index (NONE: none found).
+    constexpr uint32_t NONE = 0xffffffffu;
+    uint32_t axis = 0u;
+    float dir = 1.f;
+    if (n >= 2u) {
+        const float2 p = pts[0], q = pts[1];
+        axis = fabsf(q.y - p.y) > fabsf(q.x - p.x) ? 1u : 0u;
+        dir = (axis ? q.y - p.y : q.x - p.x) < 0.f ? -1.f : 1.f;
     }
-    if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) take(pts[n - 1].x, pts[n - 1].y);
+    auto probe = [&](uint32_t i) -> uint32_t {
+        if (i + 1u >= n) return NONE;
+        const float2 p = pts[i], q = pts[i + 1u];
+        return (axis ? q.y - p.y : q.x - p.x) * dir < 0.f ? i : NONE;
+    };
+    auto block_min = [&](uint32_t k) -> uint32_t {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k = min(k, (uint32_t)__shfl_xor((int)k, o));
+        __syncthreads();
+        if (lane == 0) shk[wave] = k;
+        __syncthreads();
+        uint32_t r = shk[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) r = min(r, shk[w]);
+        return r;
+    };
+    uint32_t key = NONE;
+    if (!a.no_lattice && n >= 64u) {
+        key = block_min(min(probe(tid), probe(tid + 1024u)));
+        if (key == NONE && n > LAT_SEARCH0 + 1u) {
+            uint32_t k2 = NONE;
+#pragma unroll 2
+            for (uint32_t i = LAT_SEARCH0 + tid; i < LAT_SEARCH1; i += 1024u) k2 = min(k2, probe(i));
+            key = block_min(k2);
+        }
+    }
+    const uint32_t rf = key == NONE ? 0u : key + 1u;
+    const uint32_t rs = rf ? n / rf : 0u;
+    const bool cand = rf >= 8u && (rf & 7u) == 0u && rs * rf == n && (rs & 7u) == 0u;      // block-uniform
+    if (blockIdx.x == 0 && tid == 0) {
+        a.sparams->lat_cand[0] = cand ? rf : 0u;
+        a.sparams->lat_cand[1] = axis;
+    }
+    float wmax = 0.f, hmax = 0.f;              // widest / tallest index tile this wave met (wave-uniform)
+    if (cand) {
+        const uint32_t ntx = rf >> 3, nty = rs >> 3, ntiles = ntx * nty;
+        const uint32_t gw = blockIdx.x * 16u + (uint32_t)wave, nw = gridDim.x * 16u;
+        for (uint32_t t0 = gw; t0 < ntiles; t0 += 4u * nw) {
+            float2 p[4];
+            uint32_t m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t t = t0 + (uint32_t)k * nw;
+                uint32_t tx = 0, ty = 0;
+                lattice_tile_xy(t < ntiles ? t : t0, ntx, nty, tx, ty);
+                m[k] = lattice_index(tx, ty, (uint32_t)lane, rf);
+                p[k] = pts[m[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t t = t0 + (uint32_t)k * nw;
+                if (t >= ntiles) break;                 // wave-uniform
+                take(p[k].x, p[k].y);
+                float bx0 = p[k].x, bx1 = p[k].x, by0 = p[k].y, by1 = p[k].y;
+                row_box_dpp(bx0, bx1, by0, by1);
+                wave_box_from_rows_dpp(bx0, bx1, by0, by1);
+                const float w = bx1 - bx0, h = by1 - by0;      // NaN / inf coordinates: never compact
+                wmax = w == w ? fmaxf(wmax, w) : INF;
+                hmax = h == h ? fmaxf(hmax, h) : INF;
+                SPoint sp;
+                sp.x = p[k].x; sp.y = p[k].y; sp.m = m[k];
+                a.spts[(size_t)t * TILE_POINTS + (uint32_t)lane] = sp;
+            }
+        }
+    } else {
+        const float4* pts2 = (const float4*)a.samples;
+        const uint32_t npair = n / 2;                 // float4 = two points
+        const uint32_t stride = gridDim.x * BBOX_THREADS;
+        for (uint32_t i = blockIdx.x * BBOX_THREADS + tid; i < npair; i += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = i + k * stride;
+                v[k] = pts2[j < npair ? j : i];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
+        }
+        if ((n & 1u) && blockIdx.x == 0 && tid == 0) take(pts[n - 1].x, pts[n - 1].y);
+    }
     x0 = wave_min_bcast(x0); y0 = wave_min_bcast(y0);
     x1 = wave_max_bcast(x1); y1 = wave_max_bcast(y1);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {
+    if (lane == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; sh[wave][4] = wmax; sh[wave][5] = hmax; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) {
             x0 = fminf(x0, sh[w][0]); y0 = fminf(y0, sh[w][1]);
             x1 = fmaxf(x1, sh[w][2]); y1 = fmaxf(y1, sh[w][3]);
+            wmax = fmaxf(wmax, sh[w][4]); hmax = fmaxf(hmax, sh[w][5]);
         }
         a.sboxes[blockIdx.x] = make_float4(x0, y0, x1, y1);
+        a.slat[blockIdx.x] = make_float2(wmax, hmax);
     }
 }
 
@@ -157,28 +282,41 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
 // are zeroed by this one
 __global__ __launch_bounds__(256) void plan_zero_kernel(BuildArgs a) {
     zero_words(a.counts, a.zero_words);
+    if (a.zero_gacc) zero_words((uint32_t*)a.gacc, 8u * a.N);
     if (blockIdx.x == 0 && threadIdx.x < PLAN_BAR_WORDS) a.params->bar[threadIdx.x] = 0u;
 }
 
 // every workgroup of the count kernel reduces the PLAN_BBOX_BLOCKS partials (4 KB, L2 resident)
-__device__ __forceinline__ void reduce_boxes(const float4* boxes, float* sbox, float (*sh)[4]) {
+// sbox[0..3] = the box; sbox[4], sbox[5] = the widest / tallest index tile (meaningful when the first launch had a
+// lattice candidate; a NaN partial cannot occur: the first launch turns it into +inf)
+__device__ __forceinline__ void reduce_boxes(const float4* boxes, const float2* lat, float* sbox, float (*sh)[6]) {
     static_assert(PLAN_BBOX_BLOCKS == 256, "one partial per thread");
     const float4 p = boxes[threadIdx.x];
-    float v[4] = {p.x, p.y, p.z, p.w};
+    const float2 l = lat[threadIdx.x];
+    float v[6] = {p.x, p.y, p.z, p.w, l.x, l.y};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (k & 2) ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
+    for (int k = 0; k < 6; ++k) v[k] = (k & 2) || k >= 4 ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sh[wave][k] = v[k];
+        for (int k = 0; k < 6; ++k) sh[wave][k] = v[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 6; ++k) {
         float r = sh[0][k];
-        for (int w = 1; w < 4; ++w) r = (k & 2) ? fmaxf(r, sh[w][k]) : fminf(r, sh[w][k]);
+        for (int w = 1; w < 4; ++w) r = (k & 2) || k >= 4 ? fmaxf(r, sh[w][k]) : fminf(r, sh[w][k]);
         sbox[k] = r;
     }
+}
+// the decision behind a lattice candidate (plan.h, SampleParams::lat): every index tile at most twice as wide and
+// as tall as its share of the bounding box (an exact lattice: 7/8 of it).  Uniform over the launch: every workgroup
+// reduces the same partials.
+__device__ __forceinline__ bool lattice_compact(const float* sbox, uint32_t rf, uint32_t rs, uint32_t axis) {
+    if (rf == 0u) return false;
+    const float ex = sbox[2] - sbox[0], ey = sbox[3] - sbox[1];
+    const float nx = (float)(axis ? rs : rf), ny = (float)(axis ? rf : rs);      // points along x / along y
+    return sbox[4] * nx <= 16.f * ex && sbox[5] * ny <= 16.f * ey;              // NaN / inf: false
 }
 
 // Launch 2: cell key of every Gaussian / point and its rank inside the cell, with ONE returning
@@ -204,7 +342,7 @@ __device__ __forceinline__ Run run_of(uint32_t k, int lane) {
 __device__ __forceinline__ void samples_hist_part(const BuildArgs& a, uint32_t w, const SampleGrid& sg, uint32_t* lh, int lane);
 
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
-    __shared__ float shb[4][4];
+    __shared__ float shb[4][6];
     __shared__ uint32_t lh[SAMPLES_COARSE_BINS];
     const int lane = threadIdx.x & 63;
     // Every dependent memory round trip costs 2-4 us in this kernel (in-kernel stamps): issue the
@@ -215,21 +353,29 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     float2 pt[4];
     const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
     const uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
-    if (gpart) {
-        if (gi < a.N) {
-            gm[0] = a.means[2 * gi]; gm[1] = a.means[2 * gi + 1];
-            gc[0] = a.conics[3 * gi]; gc[1] = a.conics[3 * gi + 1]; gc[2] = a.conics[3 * gi + 2];
-        }
-    } else if (!a.coarse) {
+    // the first launch's lattice candidate (plan.h): with one, the sample workgroups most likely have nothing to do
+    const uint32_t lat_rf = a.do_samples ? a.sparams->lat_cand[0] : 0u;
+    const uint32_t lat_axis = a.do_samples ? a.sparams->lat_cand[1] : 0u;
+    auto load_points = [&]() {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t i = i0 + 64 * k;
             pt[k] = i < a.M ? ((const float2*)a.samples)[i] : make_float2(0.f, 0.f);
         }
+    };
+    if (gpart) {
+        if (gi < a.N) {
+            gm[0] = a.means[2 * gi]; gm[1] = a.means[2 * gi + 1];
+            gc[0] = a.conics[3 * gi]; gc[1] = a.conics[3 * gi + 1]; gc[2] = a.conics[3 * gi + 2];
+        }
+    } else if (!a.coarse && lat_rf == 0u) {
+        load_points();
     }
-    float sbox[4];
+    float sbox[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool lattice = false;
     if (a.do_samples) {
-        reduce_boxes(a.sboxes, sbox, shb);
+        reduce_boxes(a.sboxes, a.slat, sbox, shb);
+        lattice = lattice_compact(sbox, lat_rf, lat_rf ? a.M / lat_rf : 0u, lat_axis);
     } else {      // the samples workspace is complete: its box is in its header
 #pragma unroll
         for (int k = 0; k < 4; ++k) sbox[k] = a.sparams->box[k];
@@ -242,6 +388,8 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             for (int k = 0; k < 4; ++k) a.sparams->box[k] = sbox[k];
             a.sparams->sg = sg;
             a.sparams->scan_error = 0;
+            a.sparams->lat[0] = lattice ? lat_rf : 0u;
+            a.sparams->lat[1] = lattice ? a.M / lat_rf : 0u;
         }
         if (a.do_plan) {
             a.params->gg = g;
@@ -279,9 +427,12 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
         base = __shfl(base, r.start);
         if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
+    } else if (lattice) {
+        // index-tiled: the first launch has written `spts`; no keys, no counters (block-uniform)
     } else if (a.coarse) {
         samples_hist_part(a, blockIdx.x - gblocks, sg, lh, lane);
     } else {
+        if (lat_rf != 0u) load_points();      // a candidate that was not compact after all: the loads were not issued early
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
         uint32_t id[4], base[4];
         Run r[4];
@@ -454,6 +605,7 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     __shared__ uint32_t sh2[4];
     const uint32_t nb0 = a.do_plan ? a.scan_blocks : 0;
     const bool seg0 = blockIdx.x < nb0;
+    if (!seg0 && a.sparams->lat[0] != 0u) return;      // index-tiled points: nothing was counted (block-uniform)
     scan_block<false>(a, seg0, seg0 ? blockIdx.x : blockIdx.x - nb0, sh, sh2);
 }
 
@@ -537,6 +689,7 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         // build into this workspace (PIGS_BUILD_PLAN_WS_CLEAN) needs no zeroing launch
         for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.zero_words; k += gridDim.x * 256) a.counts[k] = 0u;
     }
+    if (!gpart && a.sparams->lat[0] != 0u) return;     // index-tiled points: `spts` is the first launch's (block-uniform)
     if (!gpart && a.coarse && a.h_chunk <= SCATTER_STAGE_MAX) {
         // (the sample workgroups of this launch are then the chunks' workgroups: h_wgs of them)
         uint32_t* words = (uint32_t*)(scatter_stage + a.h_chunk);
@@ -564,10 +717,9 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
             a.gbox[pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], hx * 1.0001f, hy * 1.0001f);
         }
         a.g2o[pos] = i;
-        // the backward's scratch starts zeroed (and plan_unpermute_kernel re-zeroes what it
-        // reads), so the backward needs no memset launch
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a.gacc[(size_t)k * a.N + pos] = 0.f;
+        // (the backward's scratch `gacc` is zero from the workspace's first build on -- zeroed once by the first
+        // launch of a build into a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN, re-zeroed by plan_unpermute_kernel
+        // behind every backward: no memset launch, and no 8 scattered stores per Gaussian here either)
     }
     if (!gpart && i < a.M) {
         const uint2 kr = a.skey[i];
@@ -603,6 +755,7 @@ __global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
     constexpr int B = 8;                    // points a thread keeps in registers
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    if (a.sparams->lat[0] != 0u) return;               // index-tiled points: nothing to sort (block-uniform)
     const uint32_t seg0 = a.sstarts[(size_t)b * a.h_wgs];
     const uint32_t seg1 = b + 1 < SAMPLES_COARSE_BINS ? a.sstarts[(size_t)(b + 1) * a.h_wgs] : a.M;
     const uint32_t id0 = b * a.cells_per_bin, nkey = a.cells_per_bin * (uint32_t)SUB;
@@ -809,8 +962,6 @@ __global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
         if (!(hy < 3.0e38f)) hy = 3.0e38f;
         a.gbox[pos] = make_float4(mx, my, hx * 1.0001f, hy * 1.0001f);
         a.g2o[pos] = i;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a.gacc[(size_t)q * a.N + pos] = 0.f;
     }
     // ---- the last workgroup out re-arms the barriers for the next build into this workspace
     __syncthreads();
@@ -843,36 +994,6 @@ __device__ __forceinline__ uint32_t xcd_block_chunk(uint32_t nblocks) {      // 
     }
 }
 __device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) { return xcd_block_chunk<PIGS_XCD_CHUNK>(nblocks); }
-
-// Bounding boxes with the DPP modifier fused into the min / max (hipcc emits v_mov_dpp + a
-// canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  The four
-// reductions are independent chains and are interleaved step by step, so the two wait states a
-// DPP read needs after the VALU write of its source are filled by the other three chains: one
-// s_nop at the head instead of one per step (an s_nop costs an issue slot like a VALU
-// instruction).  row_box_dpp leaves in every lane the box of the lane's own 16-lane row;
-// wave_box_dpp continues from there to the box of the wave, broadcast from lane 63.
-#define PIGS_BOX_STEP(MOD)                                \
-    "v_min_f32_dpp %0, %0, %0 " MOD " bank_mask:0xf\n\t" \
-    "v_max_f32_dpp %1, %1, %1 " MOD " bank_mask:0xf\n\t" \
-    "v_min_f32_dpp %2, %2, %2 " MOD " bank_mask:0xf\n\t" \
-    "v_max_f32_dpp %3, %3, %3 " MOD " bank_mask:0xf\n\t"
-__device__ __forceinline__ void row_box_dpp(float& x0, float& x1, float& y0, float& y1) {
-    asm volatile("s_nop 1\n\t"
-                 PIGS_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf")
-                 PIGS_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf")
-                 PIGS_BOX_STEP("row_half_mirror row_mask:0xf")
-                 PIGS_BOX_STEP("row_mirror row_mask:0xf")
-                 "s_nop 1"
-                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
-}
-__device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, float& y0, float& y1) {
-    asm volatile("s_nop 1\n\t"
-                 PIGS_BOX_STEP("row_bcast:15 row_mask:0xa")
-                 PIGS_BOX_STEP("row_bcast:31 row_mask:0xc")
-                 "s_nop 1"
-                 : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
-    x0 = readlane_f(x0, 63); x1 = readlane_f(x1, 63); y0 = readlane_f(y0, 63); y1 = readlane_f(y1, 63);
-}
 
 // ------------------------------------------------------------------------------------------
 // Launch 5 of a plan build: the tile lists.  One wave = LISTS_TPW consecutive tiles (4 tiles = 256
@@ -907,17 +1028,10 @@ struct ListArgs {
     float q_f;            // the narrow cut-off (pv.q_max is the wide one)
 };
 
-__global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
-    __shared__ ListsLds lds_all[4];
+// the lists of the LISTS_TPW tiles from tile0 (one wave)
+__device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& lds, uint32_t tile0, int lane) {
     const PlanView& pv = a.pv;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the same strips of the domain on the same XCD as in the sampling kernels, which then find a tile's
-    // lists in the L2 that wrote them (a workgroup here is 4 * LISTS_TPW tiles; forward 27.05 -> 26.4 us)
-    const uint32_t tile0 = (xcd_block_chunk<PIGS_XCD_CHUNK / LISTS_TPW>(gridDim.x) * 4 + (uint32_t)wave) * LISTS_TPW;
     const uint32_t ntiles = a.sv.ntiles;
-    if (tile0 >= ntiles) return;
-    ListsLds& lds = lds_all[wave];
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
     const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
@@ -1253,6 +1367,20 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     }
 }
 
+// the same strips of the domain on the same XCD as in the sampling kernels, which then find a tile's
+// lists in the L2 that wrote them (a workgroup here is 4 * LISTS_TPW tiles; forward 27.05 -> 26.4 us)
+__device__ __forceinline__ uint32_t lists_tile0(int wave) {
+    return (xcd_block_chunk<PIGS_XCD_CHUNK / LISTS_TPW>(gridDim.x) * 4 + (uint32_t)wave) * LISTS_TPW;
+}
+__global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
+    __shared__ ListsLds lds_all[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = lists_tile0(wave);
+    if (tile0 >= a.sv.ntiles) return;
+    build_block_lists(a, lds_all[wave], tile0, lane);
+}
+
 // ------------------------------------------------------------------------------------------
 // Sampling kernels.  One wave = one tile.
 // ------------------------------------------------------------------------------------------
@@ -1443,65 +1571,60 @@ constexpr int fwd_waves() {
     constexpr int n = FwdLayout<2, C, MASK>::N;
     return n > 12 ? 4 : n > 10 ? 5 : (C == 1 && (MASK == 7 || MASK == 19 || MASK == 1 || MASK == ORDR)) ? PIGS_FWD_WAVES : 6;
 }
+constexpr bool fwd_can_stage(int C, int MASK) { return C == 1 && (MASK == 7 || MASK == 19); }
+// staged outputs (PlanView::stage): one record per point at its original index instead of the three stores
 template <int C, int MASK>
-__global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) void tile_forward_kernel(
-    PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
-    float* __restrict__ o3, Resid<float> rz) {
+__device__ __forceinline__ void stage_store(const PlanView& pv, const float* acc, uint32_t m) {
+    using L = FwdLayout<2, C, MASK>;
+    if constexpr (C == 1 && MASK == 7) {
+        pv.stage[2 * (size_t)m] = make_float4(acc[L::O0], -acc[L::O1], -acc[L::O1 + 1], acc[L::O2]);
+        pv.stage[2 * (size_t)m + 1] = make_float4(acc[L::O2 + 1], acc[L::O2 + 1], acc[L::O2 + 2], 0.f);
+    } else if constexpr (C == 1 && MASK == 19) {
+        pv.stage[2 * (size_t)m] = make_float4(acc[L::O0], -acc[L::O1], -acc[L::O1 + 1], acc[L::O2]);
+    }
+}
+
+// TILE_MODE_POINTS (plan.h): four points of tile `tile` at a time (quad = 0 .. 15), 16 lanes per point, lane = candidate
+template <int C, int MASK>
+__device__ __forceinline__ void forward_points_quad(const PlanView& pv, const SamplesView& sv, uint32_t tile, uint32_t quad, int lane,
+                                                    float q_f, float* __restrict__ o0, float* __restrict__ o1,
+                                                    float* __restrict__ o2, float* __restrict__ o3, const Resid<float>& rz) {
+    using L = FwdLayout<2, C, MASK>;
+    const int row = lane >> 4, i = lane & 15;
+    const uint32_t m = tile * TILE_POINTS + quad * 4u + (uint32_t)row;
+    const bool valid = m < sv.M;
+    const SPoint sp = sv.spts[valid ? m : sv.M - 1];
+    const float s[2] = {sp.x, sp.y};
+    float acc[L::N];
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
+    // !(q > cut): a degenerate conic (NaN) is evaluated, as the list build's tests would have kept it
+    walk_point<16>(pv, sp.x, sp.y, i, [&](uint32_t, const float4 A, const float4 B) {
+        if (!(pair_q(A, B, sp.x, sp.y) > q_f)) {
+            const Rec r = make_rec(A, B);
+            fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v, &rz);
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < L::N; ++k) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
+    }
+    if (i == 0 && valid) {
+        if (fwd_can_stage(C, MASK) && pv.stage) stage_store<C, MASK>(pv, acc, sp.m);
+        else fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
+    }
+}
+
+// one tile (one wave) through its group lists / record ranges; a tile in TILE_MODE_POINTS is left to the caller
+template <int C, int MASK>
+__device__ __forceinline__ void forward_tile(const PlanView& pv, const SamplesView& sv, uint32_t tile, int lane, FwdLds& lds,
+                                             float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
+                                             float* __restrict__ o3, const Resid<float>& rz) {
     using L = FwdLayout<2, C, MASK>;
     constexpr int U = PIGS_FWD_UNROLL;
-    constexpr uint32_t FW = PIGS_FWD_WG_WAVES;
-    // staged outputs (PlanView::stage): one record per point at its original index instead of the three stores
-    auto stage_store = [&](const float* acc, uint32_t m) {
-        if constexpr (C == 1 && MASK == 7) {
-            pv.stage[2 * (size_t)m] = make_float4(acc[L::O0], -acc[L::O1], -acc[L::O1 + 1], acc[L::O2]);
-            pv.stage[2 * (size_t)m + 1] = make_float4(acc[L::O2 + 1], acc[L::O2 + 1], acc[L::O2 + 2], 0.f);
-        } else if constexpr (C == 1 && MASK == 19) {
-            pv.stage[2 * (size_t)m] = make_float4(acc[L::O0], -acc[L::O1], -acc[L::O1 + 1], acc[L::O2]);
-        }
-    };
-    constexpr bool CAN_STAGE = C == 1 && (MASK == 7 || MASK == 19);
-    __shared__ FwdLds lds_all[FW];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t nmain = (sv.ntiles + FW - 1u) / FW;
-    if (blockIdx.x >= nmain) {
-        // helper workgroups (plan.h, TILE_MODE_POINTS): four points at a time, 16 lanes per point, lane = candidate
-        const uint32_t n = pv.params->n_points;
-        if (n == 0u) return;
-        const float q_f = pv.params->q_f;
-        const int row = lane >> 4, i = lane & 15;
-        const uint32_t hw = (blockIdx.x - nmain) * FW + (uint32_t)wave, nhw = (gridDim.x - nmain) * FW;
-        for (uint32_t qd = hw; qd < n * 16u; qd += nhw) {
-            const uint32_t m = pv.ptiles[qd >> 4] * TILE_POINTS + (qd & 15u) * 4u + (uint32_t)row;
-            const bool valid = m < sv.M;
-            const SPoint sp = sv.spts[valid ? m : sv.M - 1];
-            const float s[2] = {sp.x, sp.y};
-            float acc[L::N];
-#pragma unroll
-            for (int k = 0; k < L::N; ++k) acc[k] = 0.f;
-            // !(q > cut): a degenerate conic (NaN) is evaluated, as the list build's tests would have kept it
-            walk_point<16>(pv, sp.x, sp.y, i, [&](uint32_t, const float4 A, const float4 B) {
-                if (!(pair_q(A, B, sp.x, sp.y) > q_f)) {
-                    const Rec r = make_rec(A, B);
-                    fwd_accumulate<float, 2, C, MASK>(acc, s, r.mu, r.con, r.v, &rz);
-                }
-            });
-#pragma unroll
-            for (int k = 0; k < L::N; ++k) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
-            }
-            if (i == 0 && valid) {
-                if (CAN_STAGE && pv.stage) stage_store(acc, sp.m);
-                else fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
-            }
-        }
-        return;
-    }
-    const uint32_t tile = xcd_block_chunk<PIGS_XCD_CHUNK * 4 / FW>(nmain) * FW + (uint32_t)wave;
-    if (tile >= sv.ntiles) return;
+    constexpr bool CAN_STAGE = fwd_can_stage(C, MASK);
     __builtin_amdgcn_s_setprio(3);
-    FwdLds& lds = lds_all[wave];
     char* const qbase = (char*)lds.rec;
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
     const bool valid = m < sv.M;
@@ -1544,7 +1667,7 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
 #endif
     };
     if ((h0 >> TILE_MODE_SHIFT) == TILE_MODE_POINTS) {
-        return;                                   // scattered points: the helper workgroups do this tile (above)
+        return;                                   // scattered points: the caller's (helper workgroups / the fused launch's own walk)
     } else if ((h0 >> TILE_MODE_SHIFT) != TILE_MODE_RANGES) {            // LIST or GROUPS: the group lists are there
         const uint32_t ng = hd[1 + g];                                    // this row's list length
         const uint32_t* gl = pv.glist + ((size_t)tile * 4 + g) * pv.list_cap;
@@ -1623,13 +1746,76 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
     const uint32_t dist = sp.m > m_other ? sp.m - m_other : m_other - sp.m;
     const bool stream = __builtin_popcountll(__ballot(valid && dist == 1u)) >= 48;
     if (CAN_STAGE && pv.stage) {
-        if (valid) stage_store(acc, sp.m);
+        if (valid) stage_store<C, MASK>(pv, acc, sp.m);
     } else if (valid) {
         if (stream) {
             fwd_store<float, 2, C, MASK, true>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
             asm volatile("" ::: "memory");       // keeps the two branches' stores apart: merged into a common tail they lose the hint
         } else {
             fwd_store<float, 2, C, MASK, false>(acc, (int64_t)sp.m, o0, o1, o2, o3, &rz);
+        }
+    }
+}
+
+template <int C, int MASK>
+__global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) void tile_forward_kernel(
+    PlanView pv, SamplesView sv, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2,
+    float* __restrict__ o3, Resid<float> rz) {
+    constexpr uint32_t FW = PIGS_FWD_WG_WAVES;
+    __shared__ FwdLds lds_all[FW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nmain = (sv.ntiles + FW - 1u) / FW;
+    if (blockIdx.x >= nmain) {
+        // helper workgroups (plan.h, TILE_MODE_POINTS): four points at a time, 16 lanes per point, lane = candidate
+        const uint32_t n = pv.params->n_points;
+        if (n == 0u) return;
+        const float q_f = pv.params->q_f;
+        const uint32_t hw = (blockIdx.x - nmain) * FW + (uint32_t)wave, nhw = (gridDim.x - nmain) * FW;
+        for (uint32_t qd = hw; qd < n * 16u; qd += nhw)
+            forward_points_quad<C, MASK>(pv, sv, pv.ptiles[qd >> 4], qd & 15u, lane, q_f, o0, o1, o2, o3, rz);
+        return;
+    }
+    const uint32_t tile = xcd_block_chunk<PIGS_XCD_CHUNK * 4 / FW>(nmain) * FW + (uint32_t)wave;
+    if (tile >= sv.ntiles) return;
+    forward_tile<C, MASK>(pv, sv, tile, lane, lds_all[wave], o0, o1, o2, o3, rz);
+}
+
+// ------------------------------------------------------------------------------------------
+// The FIRST forward of a plan in the launch that builds its tile lists (PIGS_BUILD_DEFER_LISTS; round 4).  The
+// list build is a chain of dependent loads (a wave issues in 38 % of its cycles), the forward is float32
+// arithmetic: in two launches neither hides the other, and the forward's own first loads have nothing to hide
+// behind.  Here a wave builds the lists of its four tiles (written out as ever: the backward and every further
+// sample_*() of the same preprocess read them) and evaluates those tiles at once -- while it computes, the other
+// waves of its SIMD are still walking the grid.  One kernel boundary and the forward's cold start go away.
+// A tile in TILE_MODE_POINTS is walked by its own wave here (the helper workgroups of the two-launch path read a
+// queue that is complete only when this launch ends): right, and slower for clouds with thin outskirts -- the
+// hosts defer the lists for every plan all the same, because a cloud's first step is one of thousands.
+// ------------------------------------------------------------------------------------------
+template <int C, int MASK>
+__global__ __launch_bounds__(256) void plan_lists_forward_kernel(ListArgs a, float* __restrict__ o0, float* __restrict__ o1,
+                                                                 float* __restrict__ o2, float* __restrict__ o3, Resid<float> rz) {
+    __shared__ ListsLds lds_all[4];
+    static_assert(sizeof(FwdLds) <= sizeof(ListsLds), "the forward's queues live in the list build's LDS");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile0 = lists_tile0(wave);
+    const uint32_t ntiles = a.sv.ntiles;
+    if (tile0 >= ntiles) return;
+    build_block_lists(a, lds_all[wave], tile0, lane);
+    // what this wave's lanes stored (headers, group lists) is read back by other lanes of it: the stores have
+    // reached the L2 before the first load is issued
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    FwdLds& flds = *reinterpret_cast<FwdLds*>(&lds_all[wave]);
+    for (int t = 0; t < LISTS_TPW; ++t) {
+        const uint32_t tile = tile0 + (uint32_t)t;
+        if (tile >= ntiles) break;
+        const uint32_t h0 = __hip_atomic_load(a.pv.hdr + (size_t)tile * TILE_HDR_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((h0 >> TILE_MODE_SHIFT) == TILE_MODE_POINTS) {
+            for (uint32_t quad = 0; quad < 16u; ++quad) forward_points_quad<C, MASK>(a.pv, a.sv, tile, quad, lane, a.q_f, o0, o1, o2, o3, rz);
+        } else {
+            forward_tile<C, MASK>(a.pv, a.sv, tile, lane, flds, o0, o1, o2, o3, rz);
         }
     }
 }
@@ -2214,6 +2400,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
 
 size_t samples_error_offset() { return offsetof(SampleParams, scan_error); }
 size_t plan_error_offset() { return offsetof(PlanParams, scan_error); }
+size_t samples_lattice_offset() { return offsetof(SampleParams, lat); }
 
 int plan_layout_info(int64_t N, int64_t M, int c, int64_t* info) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
@@ -2237,6 +2424,11 @@ static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, c
     char* b = (char*)sws;
     a.sparams = (SampleParams*)(b + s.off_params);
     a.sboxes = (float4*)(b + s.off_boxes);
+    a.slat = (float2*)(b + s.off_lat);
+    {
+        const char* e = getenv("PIGS_LATTICE");
+        a.no_lattice = e && e[0] == '0';
+    }
     a.skey = (uint2*)(b + s.off_skey);
     a.spts = (SPoint*)(b + s.off_spts);
     a.samples = (const float*)samples;
@@ -2422,16 +2614,126 @@ static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_
     a.q_max = q_b > q_f ? q_b : q_f;
 }
 
+// ---- deferred tile lists (PIGS_BUILD_DEFER_LISTS) ----
+// A plan built with the flag has everything but its tile lists; the first pigs_plan_forward / pigs_plan_backward /
+// pigs_residual_* call on that workspace builds them -- a forward in the SAME launch (plan_lists_forward_kernel).
+// Which workspaces are waiting is the library's to remember (the sampling entry points carry no flags): keyed by
+// the workspace's address, set or cleared by every build into it, cleared by the first sampling call.
+struct DeferredLists { float q_f, q_wide; };
+static std::mutex g_defer_mu;
+static std::unordered_map<const void*, DeferredLists> g_deferred;
+static void defer_set(const void* ws, bool on, float q_f, float q_wide) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    if (on) g_deferred[ws] = DeferredLists{q_f, q_wide};
+    else g_deferred.erase(ws);
+}
+static bool defer_take(const void* ws, DeferredLists& d) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    auto it = g_deferred.find(ws);
+    if (it == g_deferred.end()) return false;
+    d = it->second;
+    g_deferred.erase(it);
+    return true;
+}
+// ---- does a plan of these sizes hold tiles in TILE_MODE_POINTS? ----
+// The fused first forward walks such tiles in their own list wave (right, and slow when there are hundreds: the
+// thin outskirts of a clustered cloud), the two-launch path spreads them over helper workgroups.  Which one a plan
+// wants is known on the device only, so -- like the order of the points (OrderHint above) -- the library remembers,
+// per device and (N, M): behind the list build of the first two plans of a size and of every 16th, PlanParams::
+// n_points is copied to pinned memory on the build's stream (nobody waits); a first forward takes the fused launch
+// unless the last completed copy for its sizes showed such tiles.  Never inside a capture.
+struct PointsHint {
+    int device = -1;
+    int64_t N = 0, M = 0;
+    bool has_points = false, pending = false;
+    uint32_t builds = 0;
+    hipEvent_t ev = nullptr;
+    uint32_t* host = nullptr;
+    uint64_t stamp = 0;
+};
+static PointsHint g_phints[16];
+static void phint_poll(PointsHint& h) {          // g_hint_mu held
+    if (!h.pending) return;
+    const hipError_t q = hipEventQuery(h.ev);
+    (void)hipGetLastError();
+    if (q == hipSuccess) {
+        h.pending = false;
+        h.has_points = h.host[0] != 0u;
+    }
+}
+static PointsHint* phint_entry(int device, int64_t N, int64_t M, bool create) {      // g_hint_mu held
+    PointsHint* lru = nullptr;
+    for (auto& h : g_phints) {
+        if (h.device == device && h.N == N && h.M == M) { h.stamp = ++g_hint_clock; return &h; }
+        if (!h.pending && (!lru || h.stamp < lru->stamp)) lru = &h;
+    }
+    if (!create) return nullptr;
+    if (!lru) {
+        for (auto& h : g_phints) {
+            phint_poll(h);
+            if (!h.pending && (!lru || h.stamp < lru->stamp)) lru = &h;
+        }
+        if (!lru) return nullptr;
+    }
+    if (lru->ev && lru->device != device) { (void)hipEventDestroy(lru->ev); lru->ev = nullptr; }
+    if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (!lru->host && hipHostMalloc((void**)&lru->host, sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
+    lru->device = device; lru->N = N; lru->M = M; lru->has_points = false; lru->pending = false; lru->builds = 0; lru->stamp = ++g_hint_clock;
+    return lru;
+}
+static bool plan_expects_points(int64_t N, int64_t M, hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const bool cap = stream_capturing(stream);
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    PointsHint* h = phint_entry(dev, N, M, false);
+    if (!h) return false;
+    if (!cap) phint_poll(*h);
+    return h->has_points;
+}
+static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t stream) {      // behind a list build
+    if (stream_capturing(stream)) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    PointsHint* h = phint_entry(dev, p.N, p.M, true);
+    if (!h) return;
+    const uint32_t nth = h->builds++;
+    if (h->pending || (nth >= 2u && (nth & 15u) != 0u)) return;
+    const PlanParams* pp = (const PlanParams*)((const char*)ws + p.off_params);
+    if (hipMemcpyAsync(h->host, &pp->n_points, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(h->ev, stream) == hipSuccess)
+        h->pending = true;
+    (void)hipGetLastError();
+}
+
+static PlanView make_view(const PlanLayout& p, void* ws, float q_max);
+static SamplesView make_samples_view(const SamplesLayout& p, const void* sws);
+static ListArgs make_list_args(const PlanLayout& p, const SamplesLayout& s, void* ws, const void* sws, float q_f, float q_wide) {
+    ListArgs la{};
+    la.pv = make_view(p, ws, q_wide);
+    la.q_f = q_f;
+    la.sv = make_samples_view(s, sws);
+    la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
+    la.tlist = (uint32_t*)((char*)ws + p.off_tlist);
+    la.glist = (uint32_t*)((char*)ws + p.off_glist);
+    la.ptiles = (uint32_t*)((char*)ws + p.off_ptiles);
+    la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
+    return la;
+}
+static dim3 lists_grid(const SamplesLayout& s) { return dim3((s.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)); }
+
 // The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
 // (build_plan) or both in the same four launches, then the tile lists.
 static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_lookback, void* sws, size_t sws_bytes, void* ws, size_t ws_bytes, int64_t N,
                      int64_t M, int c, float q_max, float q_max_b, const void* means, const void* conics, const void* values,
-                     const void* samples, hipStream_t stream, bool build_lists = true, int order = 0) {
+                     const void* samples, hipStream_t stream, bool build_lists = true, int order = 0, bool defer_lists = false) {
     if (!samples_supported(M)) return PIGS_ERR_UNSUPPORTED;
     const SamplesLayout s = make_samples_layout(M);
     if (!sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
     BuildArgs a{};
     a.do_samples = do_samples; a.do_plan = do_plan; a.no_lookback = no_lookback;
+    a.zero_gacc = !plan_ws_clean;
     const bool coarse = do_samples && samples_take_coarse(s, order, stream);
     fill_samples_args(a, s, sws, samples, coarse);
     PlanLayout p{};
@@ -2445,7 +2747,7 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     }
     clear_hip_error();
     const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
-    if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(256), 0, stream, a);
+    if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(BBOX_THREADS), 0, stream, a);
     else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
     const uint32_t fused_blocks = gb > p.scan_blocks ? gb : p.scan_blocks;
     if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {
@@ -2468,19 +2770,11 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
                                    s.cells_per_bin * sizeof(uint32_t), stream, a);
         }
     }
-    if (do_plan && build_lists) {
-        ListArgs la{};
-        la.pv = make_view(p, ws, a.q_max);
-        la.q_f = q_max;
-        la.sv = make_samples_view(s, sws);
-        la.hdr = (uint32_t*)((char*)ws + p.off_hdr);
-        la.tlist = (uint32_t*)((char*)ws + p.off_tlist);
-        la.glist = (uint32_t*)((char*)ws + p.off_glist);
-        la.ptiles = (uint32_t*)((char*)ws + p.off_ptiles);
-        la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
-        hipLaunchKernelGGL(plan_lists_kernel, dim3((s.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)), dim3(256), 0, stream, la);
-    }
+    if (do_plan && build_lists && !defer_lists)
+        hipLaunchKernelGGL(plan_lists_kernel, lists_grid(s), dim3(256), 0, stream, make_list_args(p, s, ws, sws, q_max, a.q_max));
     const int rc = launch_status();
+    if (do_plan) defer_set(ws, build_lists && defer_lists && rc == PIGS_OK, q_max, a.q_max);
+    if (do_plan && build_lists && !defer_lists && rc == PIGS_OK) plan_note_points(p, ws, stream);
     if (do_samples && rc == PIGS_OK && order == 0) samples_note_order(s, sws, stream);
     return rc;
 }
@@ -2516,12 +2810,15 @@ int plan_build(void* ws, size_t ws_bytes, void* sws, size_t sws_bytes, int flags
                float q_max, float q_max_backward, const void* means, const void* conics, const void* values, const void* samples,
                hipStream_t stream) {
     return run_build((flags & 1) != 0, true, (flags & 2) != 0, (flags & 4) != 0, sws, sws_bytes, ws, ws_bytes, N, M, c, q_max, q_max_backward, means, conics, values,
-                     samples, stream, true, (flags & 8) ? 1 : (flags & 16) ? 2 : 0);
+                     samples, stream, true, (flags & 8) ? 1 : (flags & 16) ? 2 : 0, (flags & PIGS_BUILD_DEFER_LISTS) != 0);
 }
+
+// the masks the fused first forward is compiled for (the rest: the list launch, then the forward launch)
+template <int C> static bool fused_first_compiled(int mask) { return C == 1 ? (mask == 1 || mask == 7 || mask == 19 || mask == 32) : mask == 7; }
 
 template <int C>
 static int plan_forward_c(const PlanView& pv_in, const SamplesView& sv, int mask, float* const* out, hipStream_t stream,
-                          const Resid<float>& rz) {
+                          const Resid<float>& rz, const ListArgs* first = nullptr) {
     // + the helper workgroups of the TILE_MODE_POINTS tiles (they leave at once when the plan queued none)
     const dim3 grid((sv.ntiles + PIGS_FWD_WG_WAVES - 1) / PIGS_FWD_WG_WAVES + POINT_HELPER_BLOCKS * 4 / PIGS_FWD_WG_WAVES),
         block(64 * PIGS_FWD_WG_WAVES);
@@ -2530,12 +2827,35 @@ static int plan_forward_c(const PlanView& pv_in, const SamplesView& sv, int mask
     const bool staged = C == 1 && (mask == 7 || mask == 19) && points_unordered(sv.M, stream);
     if (!staged) pv.stage = nullptr;
     clear_hip_error();
+    bool done = false;
+    if (first) {
+        // the plan's tile lists are still to be built (PIGS_BUILD_DEFER_LISTS): in this launch where a fused kernel
+        // is compiled for the mask, in a launch of their own in front of the forward otherwise
+        ListArgs la = *first;
+        la.pv.stage = pv.stage;
+        const dim3 lgrid((sv.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW));
+#define PIGS_FUSED(MK)                                                                                                  \
+    case MK:                                                                                                            \
+        hipLaunchKernelGGL((plan_lists_forward_kernel<C, MK>), lgrid, dim3(256), 0, stream, la, out[0], out[1], out[2], \
+                           out[3], rz);                                                                                 \
+        done = true;                                                                                                    \
+        break;
+        if (fused_first_compiled<C>(mask) && !getenv("PIGS_NO_FUSED_FIRST") && !plan_expects_points(pv.N, sv.M, stream)) {
+            if constexpr (C == 1) {
+                switch (mask) { PIGS_FUSED(1) PIGS_FUSED(7) PIGS_FUSED(19) PIGS_FUSED(32) }
+            } else {
+                switch (mask) { PIGS_FUSED(7) }
+            }
+        }
+#undef PIGS_FUSED
+        if (!done) hipLaunchKernelGGL(plan_lists_kernel, lgrid, dim3(256), 0, stream, la);
+    }
 #define PIGS_CASE(MK)                                                                                          \
     case MK:                                                                                                   \
         hipLaunchKernelGGL((tile_forward_kernel<C, MK>), grid, block, 0, stream, pv, sv, out[0], out[1], out[2], \
                            out[3], rz);                                                                        \
         break;
-    switch (mask) {
+    if (!done) switch (mask) {
         PIGS_CASE(1) PIGS_CASE(2) PIGS_CASE(4) PIGS_CASE(8) PIGS_CASE(7) PIGS_CASE(15) PIGS_CASE(16) PIGS_CASE(19) PIGS_CASE(32)
         default: return PIGS_ERR_UNSUPPORTED;
     }
@@ -2601,11 +2921,15 @@ int plan_forward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, i
     float* o[4];
     for (int k = 0; k < 4; ++k) o[k] = mask_uses_slot(mask, k) ? (float*)out[k] : nullptr;
     const int cm = covering_mask_of(mask);
-    switch (c) {
-        case 1: return plan_forward_c<1>(pv, sv, cm, o, stream, resid_of(resid, target));
-        case 2: return plan_forward_c<2>(pv, sv, cm, o, stream, resid_of(resid, target));
-    }
-    return PIGS_ERR_UNSUPPORTED;
+    if (c != 1 && c != 2) return PIGS_ERR_UNSUPPORTED;
+    DeferredLists d{};
+    ListArgs la{};
+    const bool first = defer_take(ws, d);
+    if (first) la = make_list_args(p, s, ws, sws, d.q_f, d.q_wide);
+    const int rc = c == 1 ? plan_forward_c<1>(pv, sv, cm, o, stream, resid_of(resid, target), first ? &la : nullptr)
+                          : plan_forward_c<2>(pv, sv, cm, o, stream, resid_of(resid, target), first ? &la : nullptr);
+    if (first && rc == PIGS_OK) plan_note_points(p, ws, stream);
+    return rc;
 }
 
 int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, int64_t N, int64_t M, int c,
@@ -2617,6 +2941,16 @@ int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, 
     if (!ws || ws_bytes < p.total_bytes || !sws || sws_bytes < s.total_bytes) return PIGS_ERR_WORKSPACE;
     const PlanView pv = make_view(p, ws, q_max);
     const SamplesView sv = make_samples_view(s, sws);
+    {   // a backward as the first sampling call on a plan with deferred lists: the list launch first
+        DeferredLists d{};
+        if (defer_take(ws, d)) {
+            clear_hip_error();
+            hipLaunchKernelGGL(plan_lists_kernel, lists_grid(s), dim3(256), 0, stream, make_list_args(p, s, ws, sws, d.q_f, d.q_wide));
+            const int rc = launch_status();
+            if (rc != PIGS_OK) return rc;
+            plan_note_points(p, ws, stream);
+        }
+    }
     const float* g[4];
     for (int k = 0; k < 4; ++k) g[k] = mask_uses_slot(mask, k) ? (const float*)gout[k] : nullptr;
     const int cm = covering_mask_of(mask);

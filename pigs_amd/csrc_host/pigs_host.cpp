@@ -184,7 +184,7 @@ struct Plan {
 std::shared_ptr<Plan> build_plan(const at::Tensor& means, const at::Tensor& values, const at::Tensor& conics,
                                  const at::Tensor& samples, float q_max, float q_max_backward,
                                  std::shared_ptr<SamplePlan> sp, const at::Tensor& source,
-                                 const std::shared_ptr<PlanPool>& pool_or_null) {
+                                 const std::shared_ptr<PlanPool>& pool_or_null, bool defer_lists) {
     auto plan = std::make_shared<Plan>();
     plan->N = means.size(0); plan->M = samples.size(0); plan->c = (int)values.size(1); plan->q_max = q_max;
     plan->q_max_backward = q_max_backward > q_max ? q_max_backward : q_max;
@@ -199,6 +199,8 @@ std::shared_ptr<Plan> build_plan(const at::Tensor& means, const at::Tensor& valu
     plan->build_stream = stream;
     plan->key = PlanPool::Key(plan->N, plan->M, plan->c, (int)means.device().index(), (void*)stream);
     int flags = sp->built ? 0 : PIGS_BUILD_SAMPLES;
+    // the tile lists are built by the plan's first sampling call, a forward in the same launch (pigs_amd.h)
+    if (defer_lists) flags |= PIGS_BUILD_DEFER_LISTS;
     if (pool_or_null) plan->workspace = pool_or_null->take(plan->key);
     if (plan->workspace.defined()) flags |= PIGS_BUILD_PLAN_WS_CLEAN;
     else plan->workspace = at::empty({(int64_t)nbytes}, means.options().dtype(at::kByte));
@@ -252,10 +254,21 @@ Outs forward_raw(const at::Tensor& means, const at::Tensor& values, const at::Te
     return outs;
 }
 
+// The three parameter gradients as views of ONE flat allocation [means | values | conics]: the multi-GPU path
+// (pigs_amd/distributed.py) all-reduces that buffer in place -- no packing copy in front of the collective, no
+// slicing behind it.
+std::array<at::Tensor, 3> gradient_views(const at::Tensor& means, const at::Tensor& values, const at::Tensor& conics) {
+    const int64_t nm = means.numel(), nv = values.numel(), nc = conics.numel();
+    at::Tensor flat = at::empty({nm + nv + nc}, means.options());
+    return {flat.narrow(0, 0, nm).view(means.sizes()), flat.narrow(0, nm, nv).view(values.sizes()),
+            flat.narrow(0, nm + nv, nc).view(conics.sizes())};
+}
+
 std::array<at::Tensor, 3> backward_raw(const at::Tensor& means, const at::Tensor& values, const at::Tensor& conics,
                                        const at::Tensor& samples, const Outs& gouts, int mask, Plan* plan) {
     const int64_t N = means.size(0), d = means.size(1), c = values.size(1), M = samples.size(0);
-    at::Tensor g_means = at::empty_like(means), g_values = at::empty_like(values), g_conics = at::empty_like(conics);
+    auto gv3 = gradient_views(means, values, conics);
+    at::Tensor g_means = gv3[0], g_values = gv3[1], g_conics = gv3[2];
     if (N > 0) {
         c10::DeviceGuard guard(means.device());
         const hipStream_t stream = current_stream(means);
@@ -376,7 +389,8 @@ struct ResidualBackward : public torch::autograd::Node {
         if (grads[0].requires_grad()) throw std::runtime_error("GaussianSampler.residual() is differentiable once");
         const at::Tensor gout = grads[0].contiguous();
         const int64_t N = means.size(0), d = means.size(1), c = values.size(1), M = samples.size(0);
-        at::Tensor g_means = at::empty_like(means), g_values = at::empty_like(values), g_conics = at::empty_like(conics);
+        auto gv3 = gradient_views(means, values, conics);
+        at::Tensor g_means = gv3[0], g_values = gv3[1], g_conics = gv3[2];
         if (N > 0 && M > 0) {
             c10::DeviceGuard guard(means.device());
             const hipStream_t stream = current_stream(means);
@@ -595,6 +609,9 @@ struct Core {
     int fuse, backend;
     float q_max, q_max3, q_max_b;
     int reuse;
+    bool defer_lists = true;
+    bool static_samples = false;      // a capture may reuse a remembered (eagerly built) SamplePlan: the caller promises
+                                      // not to modify the samples tensor between replays (GraphedStep(static_samples=True))
     bool bound = false;
     at::Tensor means, values, conics, samples, samples_source;
     std::shared_ptr<Plan> plan, plan3;
@@ -684,11 +701,11 @@ struct Core {
     std::shared_ptr<Plan> make_plan(float q, std::shared_ptr<SamplePlan> sp) {
         at::AutoGradMode no_grad(false);
         const bool cap = capturing(current_stream(means));
-        if (!sp && !cap && reuse > 0)
+        if (!sp && (!cap || static_samples) && reuse > 0)
             for (auto& p : sample_plans)
-                if (p->matches(samples_source)) { sp = p; break; }
+                if (p->built && p->matches(samples_source)) { sp = p; break; }
         auto pl = build_plan(means.detach(), values.detach(), conics.detach(), samples, q, q_max_b > q ? q_max_b : q, sp,
-                             samples_source, cap ? nullptr : pool);
+                             samples_source, cap ? nullptr : pool, defer_lists);
         if (reuse > 0 && !cap) {
             std::vector<std::shared_ptr<SamplePlan>> next{pl->samples};
             for (auto& p : sample_plans)
@@ -872,6 +889,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("neighbors", &Core::neighbors)
         .def_readonly("plan", &Core::plan)
         .def_readonly("plan3", &Core::plan3)
+        .def_readwrite("defer_lists", &Core::defer_lists)
+        .def_readwrite("static_samples", &Core::static_samples)
         .def_property_readonly("sample_plans", [](const Core& c) { return c.sample_plans; })
         .def_property_readonly("pool_size", [](const Core& c) { return c.pool->size(); })
         .def("cached_orders", [](const Core& c) {

@@ -37,9 +37,26 @@ def _numel(shape):
     return n
 
 
+def _single_buffer(grads):
+    """The flat 1-D buffer that the gradients tile exactly, in order -- what the sampler's backward hands out (one
+    allocation [d means | c values | d(d+1)/2 conics per Gaussian, block after block], the three gradients views of
+    it) -- or None when they arrive any other way (accumulated by autograd, produced by torch ops, missing)."""
+    if any(g is None for g in grads):
+        return None
+    base = grads[0]._base
+    if base is None or base.dim() != 1 or not base.is_contiguous():
+        return None
+    off = base.storage_offset()
+    for g in grads:
+        if g._base is not base or not g.is_contiguous() or g.storage_offset() != off:
+            return None
+        off += g.numel()
+    return base if off == base.storage_offset() + base.numel() else None
+
+
 class _Replicated(torch.autograd.Function):
     """Identity on the replicated parameters; the backward sums their gradients over the ranks
-    with a single all-reduce of one packed buffer."""
+    with a single all-reduce of one flat buffer."""
 
     @staticmethod
     def forward(ctx, group, *params):
@@ -53,21 +70,24 @@ class _Replicated(torch.autograd.Function):
             return (None, *grads)          # single process: nothing to sum, no packing copy either
         if all(g is None for g in grads):
             return (None, *grads)
-        # one packed [N, d + d(d+1)/2 + c] buffer: whatever arrives (expanded, transposed, sliced views, or
-        # nothing at all for a parameter the loss did not touch) is laid out contiguously before the ONE
-        # collective; every rank packs the same layout, so the ranks may differ in which gradients exist
+        # ONE collective over one flat buffer laid out block after block: [means | values | conics].  The sampler's
+        # backward writes its three gradients into exactly that buffer (one allocation, three views): it is reduced
+        # in place -- no copy in, no copy out.  Whatever arrives any other way (expanded, transposed or sliced views,
+        # sums autograd accumulated, or nothing at all for a parameter the loss did not touch) is packed into the
+        # same layout first; the layout being the same, the ranks may differ in which path they take.
+        flat = _single_buffer(grads)
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+            return (None, *grads)
         shapes = ctx.shapes
-        n = shapes[0][0]
         ref = next(g for g in grads if g is not None)
-        cols = [g.reshape(n, -1) if g is not None else ref.new_zeros((n, max(1, _numel(shp) // max(n, 1))))
-                for g, shp in zip(grads, shapes)]
-        packed = torch.cat(cols, dim=1).contiguous()
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
-        out, col = [], 0
+        flat = torch.cat([g.reshape(-1) if g is not None else ref.new_zeros(_numel(shp)) for g, shp in zip(grads, shapes)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+        out, off = [], 0
         for shp in shapes:
-            w = _numel(shp) // max(n, 1)
-            out.append(packed[:, col:col + w].reshape(shp))
-            col += w
+            n = _numel(shp)
+            out.append(flat[off:off + n].view(shp))
+            off += n
         return (None, *out)
 
 

@@ -25,7 +25,13 @@ class GraphedStep:
     tensors; the same objects are returned by every replay, refreshed in place.
     """
 
-    def __init__(self, fn, make_inputs, warmup=3, device=None):
+    def __init__(self, fn, make_inputs, warmup=3, device=None, samplers=(), static_samples=False):
+        """``samplers`` / ``static_samples``: a capture records the samples build of every ``preprocess`` (a replay
+        after an in-place update of a static samples input re-sorts the points), so a replay is a cold step.  When
+        the sample points never change between replays, pass the ``GaussianSampler`` objects ``fn`` uses and
+        ``static_samples=True``: the capture then reuses the sorted sample structures the warm-up runs built, the
+        graph records the Gaussian half only (a warm step per replay), and this object keeps those structures
+        alive.  Writing to such a samples input afterwards is NOT seen by the replays."""
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs a GPU")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -37,8 +43,17 @@ class GraphedStep:
                 fn(*self.inputs)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.outputs = fn(*self.inputs)
+        was = [s.static_samples for s in samplers]
+        for s in samplers:
+            s.static_samples = bool(static_samples)
+        try:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.outputs = fn(*self.inputs)
+        finally:
+            for s, w in zip(samplers, was):
+                s.static_samples = w
+        # the graph's launches read the sample structures the capture reused: they must outlive it
+        self._keep = [list(s._sample_plans) for s in samplers] if static_samples else []
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def __call__(self):

@@ -170,10 +170,10 @@ class Plan:
     __slots__ = ("workspace", "samples", "N", "M", "c", "q_max", "q_max_backward", "_pool", "_pool_key",
                  "build_stream", "other_stream_used", "recorded_only")
 
-    BUILD_SAMPLES, WS_CLEAN = 1, 2      # pigs_amd.h: PIGS_BUILD_SAMPLES, PIGS_BUILD_PLAN_WS_CLEAN
+    BUILD_SAMPLES, WS_CLEAN, DEFER_LISTS = 1, 2, 32      # pigs_amd.h: PIGS_BUILD_SAMPLES, _PLAN_WS_CLEAN, _DEFER_LISTS
 
     def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None, pool=None,
-                 recorded_only=False, q_max_backward=None):
+                 recorded_only=False, q_max_backward=None, defer_lists=True):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
         self.q_max_backward = max(self.q_max, float(q_max_backward if q_max_backward is not None else q_max))
@@ -195,6 +195,8 @@ class Plan:
             self._pool_key = (self.N, self.M, self.c, means.device, stream.value)
             self.workspace = pool.take(self._pool_key) if pool is not None else None
             flags = 0 if sample_plan.built else self.BUILD_SAMPLES
+            if defer_lists:       # the tile lists are built by the plan's first sampling call, a forward in the same launch
+                flags |= self.DEFER_LISTS
             if self.workspace is not None:
                 flags |= self.WS_CLEAN
             else:
@@ -269,6 +271,15 @@ def forward_raw(means, values, conics, samples, mask, plan=None):
     return outs
 
 
+def _gradient_views(means, values, conics):
+    """The three parameter gradients as views of ONE flat allocation [means | values | conics]: the multi-GPU path
+    (pigs_amd/distributed.py) all-reduces that buffer in place -- no packing copy in front of the collective, no
+    slicing behind it."""
+    nm, nv, nc = means.numel(), values.numel(), conics.numel()
+    flat = torch.empty(nm + nv + nc, dtype=means.dtype, device=means.device)
+    return flat[:nm].view(means.shape), flat[nm:nm + nv].view(values.shape), flat[nm + nv:].view(conics.shape)
+
+
 def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
     """Launch the backward; ``gouts`` has 5 entries (contiguous tensor or None: orders 0..3 and the
     trace), ``mask`` marks the non-None ones.  Returns (g_means, g_values, g_conics)."""
@@ -276,9 +287,7 @@ def backward_raw(means, values, conics, samples, gouts, mask, plan=None):
     N, d = means.shape
     c = values.shape[1]
     M = samples.shape[0]
-    g_means = torch.empty_like(means)
-    g_values = torch.empty_like(values)
-    g_conics = torch.empty_like(conics)
+    g_means, g_values, g_conics = _gradient_views(means, values, conics)
     if N > 0:
         with _on_device(means.device):
             if plan is not None and M > 0:
@@ -320,7 +329,7 @@ def _residual_call(backward, means, values, conics, samples, coeffs, plan, targe
                                                _ptr(samples), cf, _ptr(target), _ptr(out), *pw, stream)
                 _lib.check(rc, "pigs_residual_forward")
             return out
-        g_means, g_values, g_conics = torch.empty_like(means), torch.empty_like(values), torch.empty_like(conics)
+        g_means, g_values, g_conics = _gradient_views(means, values, conics)
         if N > 0:
             if M > 0:
                 rc = lib.pigs_residual_backward(_DTYPES[means.dtype], d, c, N, M, _ptr(means), _ptr(conics), _ptr(values),
@@ -483,6 +492,11 @@ class GaussianSampler:
     order asked for; ``"all"`` / ``"none"`` force either behaviour.  :meth:`sample` is the
     explicit fused entry point.
 
+    ``defer_lists`` (extension, keyword only; binned path; default True): ``preprocess`` stops in front of the tile
+    lists, and the first ``sample_*`` call builds them in the same launch as its own evaluation
+    (PIGS_BUILD_DEFER_LISTS, include/pigs_amd.h: the latency-bound list build hides behind the arithmetic, one kernel
+    boundary less); ``False`` builds them in ``preprocess`` (tools that read the lists without sampling).
+
     ``host`` (extension, keyword only): ``"native"`` (default; environment override PIGS_AMD_HOST) keeps
     the sampler's state and its autograd node in the C++ torch extension ``pigs_amd/_pigs_host.so``
     (csrc_host/pigs_host.cpp) -- what the reference's own boundary is (a compiled torch extension,
@@ -504,7 +518,8 @@ class GaussianSampler:
     _warned_aggregate = False
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
-                 q_max_backward=None, reuse_samples=True, unpinned_aggregate=False, aggregate_cap=None, host=None):
+                 q_max_backward=None, reuse_samples=True, unpinned_aggregate=False, aggregate_cap=None, host=None,
+                 defer_lists=True):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):
@@ -527,6 +542,8 @@ class GaussianSampler:
         if self.q_max_backward < self.q_max:
             raise ValueError("q_max_backward must not be below q_max")
         self.reuse_samples = 4 if reuse_samples is True else max(0, int(reuse_samples))
+        self.defer_lists = bool(defer_lists)
+        self._static_samples = False
         self.unpinned_aggregate = bool(unpinned_aggregate)
         self.aggregate_cap = None if aggregate_cap is None else int(aggregate_cap)
         self._neighbors = None
@@ -543,6 +560,24 @@ class GaussianSampler:
             self._core = _load_native_host().SamplerCore(self.debug, _FUSE_CODES[fuse], _BACKEND_CODES[backend],
                                                          self.q_max, self.q_max_order3, self.q_max_backward,
                                                          self.reuse_samples)
+            self._core.defer_lists = self.defer_lists
+
+    @property
+    def static_samples(self):
+        """Settable.  While a hipGraph is being captured ``preprocess`` normally records the samples build too (a
+        replay after an in-place update of the static samples input re-sorts them), so a replay is a COLD step.
+        With ``static_samples = True`` a capture reuses the sorted sample structure that an eager ``preprocess``
+        (the capture's warm-up runs) built for the same, unmodified samples tensor: the graph holds the Gaussian
+        half only and a replay is a warm step.  The caller promises not to write to that samples tensor between
+        replays (``pigs_amd.graphs.GraphedStep(..., samplers=[...], static_samples=True)`` sets this and keeps the
+        reused structure alive)."""
+        return self._static_samples
+
+    @static_samples.setter
+    def static_samples(self, value):
+        self._static_samples = bool(value)
+        if self._core is not None:
+            self._core.static_samples = self._static_samples
 
     # state lives in the native core when there is one
     @property
@@ -642,12 +677,13 @@ class GaussianSampler:
         mc, vc, cc, sc = self._st_inputs
         capturing = torch.cuda.is_current_stream_capturing()
         sp = sample_plan
-        if sp is None and not capturing:
-            sp = next((p for p in self._st_sample_plans if p.matches(self._samples_source)), None)
+        if sp is None and (not capturing or self.static_samples):
+            sp = next((p for p in self._st_sample_plans if p.built and p.matches(self._samples_source)), None)
         pool = None if capturing else self._plan_pool
         with torch.no_grad():
             plan = Plan(mc.detach(), vc.detach(), cc.detach(), sc, q_max, sp, self._samples_source, pool,
-                        recorded_only=capturing, q_max_backward=max(q_max, self.q_max_backward))
+                        recorded_only=capturing, q_max_backward=max(q_max, self.q_max_backward),
+                        defer_lists=self.defer_lists)
         if self.reuse_samples and not capturing:
             self._st_sample_plans = [plan.samples] + [p for p in self._st_sample_plans if p is not plan.samples]
             del self._st_sample_plans[self.reuse_samples:]

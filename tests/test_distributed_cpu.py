@@ -139,3 +139,75 @@ def test_replicated_is_identity_without_process_group():
     assert torch.allclose(a.grad, torch.full_like(a, 2.0))
     assert torch.allclose(b.grad, torch.full_like(b, 3.0))
     assert torch.allclose(c.grad, 2 * c.detach())
+
+
+class _FlatGrads(torch.autograd.Function):
+    """Stands in for the sampler's backward: the three gradients are views of ONE flat allocation
+    [means | values | conics] (pigs_amd/sampler.py::_gradient_views, csrc_host/pigs_host.cpp::gradient_views)."""
+
+    @staticmethod
+    def forward(ctx, means, values, conics, w):
+        ctx.save_for_backward(means, values, conics, w)
+        return (means.sum(1) * w).sum() + (values.sum(1) * w).sum() * 2 + (conics.sum(1) * w).sum() * 3
+
+    @staticmethod
+    def backward(ctx, g):
+        means, values, conics, w = ctx.saved_tensors
+        nm, nv, nc = means.numel(), values.numel(), conics.numel()
+        flat = torch.empty(nm + nv + nc, dtype=means.dtype)
+        gm, gv, gc = flat[:nm].view(means.shape), flat[nm:nm + nv].view(values.shape), flat[nm + nv:].view(conics.shape)
+        gm.copy_((w * g)[:, None].expand_as(means))
+        gv.copy_((2 * w * g)[:, None].expand_as(values))
+        gc.copy_((3 * w * g)[:, None].expand_as(conics))
+        return gm, gv, gc, None
+
+
+def _worker_flat(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pigs_amd import distributed as D
+        g = torch.Generator().manual_seed(3)
+        means = torch.randn((11, 2), generator=g, dtype=torch.float64).requires_grad_(True)
+        values = torch.randn((11, 1), generator=g, dtype=torch.float64).requires_grad_(True)
+        conics = torch.randn((11, 3), generator=g, dtype=torch.float64).requires_grad_(True)
+        w = torch.randn((11,), generator=g, dtype=torch.float64)
+        seen = []
+        orig = D._single_buffer
+        D._single_buffer = lambda grads: seen.append(orig(grads)) or seen[-1]
+        m_r, v_r, c_r = D.replicated(means, values, conics)
+        loss = _FlatGrads.apply(m_r, v_r, c_r, w) * (rank + 1)
+        if rank == 1:
+            loss = loss + (m_r ** 2).sum()          # a second consumer: autograd sums before the collective -> the packed path
+        loss.backward()
+        out_q.put((rank, seen[0] is not None, means.grad.numpy(), values.grad.numpy(), conics.grad.numpy(),
+                   means.detach().numpy(), w.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_buffer_gradients_are_reduced_in_place_and_mix_with_the_packed_path():
+    """The sampler's backward hands out views of one flat buffer: rank 0 all-reduces it in place; rank 1's
+    gradients were summed by autograd on the way (two consumers) and take the packing path -- same layout, same
+    collective, same result on both."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] and not results[1][1]          # in place on rank 0, packed on rank 1
+    means, w = results[0][5], results[0][6]
+    exp_m = np.repeat(w[:, None], 2, 1) * 3 + 2 * means
+    exp_v = np.repeat(w[:, None], 1, 1) * 2 * 3
+    exp_c = np.repeat(w[:, None], 3, 1) * 3 * 3
+    for r in results:
+        assert np.allclose(r[2], exp_m, rtol=0, atol=1e-13)
+        assert np.allclose(r[3], exp_v, rtol=0, atol=1e-13)
+        assert np.allclose(r[4], exp_c, rtol=0, atol=1e-13)

@@ -99,3 +99,51 @@ def test_graphed_step_helper(hip_lib):
         for a, b in zip((loss, gm, gv, gc), eager):
             a, b = a.detach(), b.detach()
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30, trial
+
+
+@pytest.mark.parametrize("host", ["native", "ctypes"])
+def test_graphed_step_with_static_samples_replays_a_warm_step(hip_lib, host):
+    """GraphedStep(samplers=..., static_samples=True): the capture reuses the sorted sample structure its warm-up
+    runs built (no samples build in the graph: a replay is a warm step), keeps it alive, and stays right on new
+    parameter values -- also after eager traffic on the same sampler has evicted everything it remembered."""
+    from diff_gaussian_sampling import GaussianSampler
+    from pigs_amd.graphs import GraphedStep
+    dev = torch.device("cuda")
+    gs = synthetic.lattice_gaussians(32, 32, 0.7, seed=6)
+    gen = torch.Generator().manual_seed(17)
+    samples = (torch.rand((6000, 2), generator=gen) * 2 - 1).float().to(dev)       # points in no order: a real sort
+    sampler = GaussianSampler(False, backend="binned", fuse="all", host=host)
+
+    def make_inputs():
+        return tuple(gs[k].float().to(dev).requires_grad_(True) for k in ("means", "values", "conics"))
+
+    def fn(means, values, conics):
+        sampler.preprocess(means, values, None, conics, samples)
+        u, du, h = sampler.sample((0, 1, 2))
+        loss = ((u[:, 0] - (h[:, 0, 0, 0] + h[:, 1, 1, 0])) ** 2).mean() + (du ** 2).mean()
+        return (u, du, h) + torch.autograd.grad(loss, (means, values, conics))
+
+    step = GraphedStep(fn, make_inputs, samplers=[sampler], static_samples=True)
+    assert not sampler.static_samples                       # restored
+    captured = sampler._plan
+    assert captured.recorded_only and captured.samples.built          # the Gaussian half recorded, the samples half reused
+    assert any(captured.samples is p for keep in step._keep for p in keep)
+    other = GaussianSampler(False, backend="binned", fuse="all", host=host)
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        with torch.no_grad():
+            step.inputs[1].copy_(torch.as_tensor(rng.uniform(-1, 1, step.inputs[1].shape), dtype=torch.float32, device=dev))
+        for k in range(6):        # eager traffic: evicts the remembered sample plans, recycles pooled workspaces
+            sampler.preprocess(step.inputs[0].detach(), step.inputs[1].detach(), None, step.inputs[2].detach(),
+                               (torch.rand((6000, 2), generator=gen) * 2 - 1).float().to(dev))
+            sampler.sample_gaussians()
+        outs = step()
+        torch.cuda.synchronize()
+        m, v, c = (x.detach().clone().requires_grad_(True) for x in step.inputs)
+        other.preprocess(m, v, None, c, samples)
+        u, du, h = other.sample((0, 1, 2))
+        loss = ((u[:, 0] - (h[:, 0, 0, 0] + h[:, 1, 1, 0])) ** 2).mean() + (du ** 2).mean()
+        exp = (u, du, h) + torch.autograd.grad(loss, (m, v, c))
+        for k, (a, b) in enumerate(zip(outs, exp)):
+            a, b = a.detach(), b.detach()
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30, (trial, k)

@@ -1,0 +1,166 @@
+"""GPU: the INDEX-TILED order of a samples build (include/pigs_amd.h, pigs_samples_lattice_offset): a point set
+that arrives as a lattice in row order -- meshgrid(indexing="xy").reshape(-1, 2), the reference's own grids
+(/root/reference/test_gaussian_sampling.py:43-46, main_pn.py:317-324) -- is not sorted; its tiles are index
+arithmetic.  Results must be the oracle's whichever order the build takes, and the build must take the sort
+whenever the index tiles would not be compact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_binned_gpu import check_case, random_gaussians, rel, dev32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Sampler(hip_lib):
+    assert torch.cuda.is_available()
+    from diff_gaussian_sampling import GaussianSampler
+    return GaussianSampler
+
+
+class lattice_env:
+    """PIGS_LATTICE for the builds inside the block (read at every build)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        self.old = os.environ.get("PIGS_LATTICE")
+        if self.value is None:
+            os.environ.pop("PIGS_LATTICE", None)
+        else:
+            os.environ["PIGS_LATTICE"] = self.value
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("PIGS_LATTICE", None)
+        else:
+            os.environ["PIGS_LATTICE"] = self.old
+
+
+def lattice_of(sampler, hip_lib):
+    off = hip_lib.pigs_samples_lattice_offset()
+    ws = sampler._plan.samples.workspace
+    rf, rs = ws[off:off + 8].view(torch.int32).cpu().tolist()
+    return rf, rs
+
+
+def grid(rx, ry, indexing="xy", lo=(-1.0, -0.7), hi=(1.0, 0.9)):
+    gx, gy = np.meshgrid(np.linspace(lo[0], hi[0], rx), np.linspace(lo[1], hi[1], ry), indexing=indexing)
+    return np.stack((gx, gy), -1).reshape(-1, 2)
+
+
+CASES = [
+    ("8 x 8: one tile", grid(8, 8), (8, 8)),
+    ("64 x 64", grid(64, 64), (64, 64)),
+    ("24 x 40: odd tile counts both ways", grid(24, 40), (24, 40)),
+    ("40 x 24", grid(40, 24), (40, 24)),
+    ("8 x 200: one tile column", grid(8, 200), (8, 200)),
+    ("264 x 8: one tile row", grid(264, 8), (264, 8)),
+    ("ij order (y fastest)", grid(48, 32, indexing="ij"), (32, 48)),
+    ("3000 x 8: row longer than the first search window", grid(3000, 8), (3000, 8)),
+    ("100 x 100: not multiples of 8", grid(100, 100), (0, 0)),
+    ("60 x 64", grid(60, 64), (0, 0)),
+    ("64 x 60", grid(64, 60), (0, 0)),
+]
+
+
+@pytest.mark.parametrize("name,pts,want", CASES, ids=[c[0] for c in CASES])
+def test_lattices_are_index_tiled_and_match_the_oracle(Sampler, hip_lib, name, pts, want):
+    rng = np.random.default_rng(7)
+    means, con, values = random_gaussians(rng, 600, 1, log_sigma_mean=-2.6, log_sigma_std=0.5)
+    s = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
+    assert lattice_of(s, hip_lib) == want
+    with lattice_env("0"):
+        s = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
+        assert lattice_of(s, hip_lib) == (0, 0)
+
+
+def test_a_lattice_candidate_that_is_not_compact_is_sorted(Sampler, hip_lib):
+    """The first descent says 64 points per row and 64 rows -- but the rows come in no order (a tile of 8 index
+    rows spans the domain): the build must fall back to the sort, and be right either way."""
+    rng = np.random.default_rng(11)
+    means, con, values = random_gaussians(rng, 500, 1, log_sigma_mean=-2.6, log_sigma_std=0.4)
+    g = grid(64, 64).reshape(64, 64, 2)
+    rows = rng.permutation(64)
+    rows = np.concatenate(([0], rows[rows != 0]))        # row 0 stays first: the candidate is found
+    scrambled = g[rows].reshape(-1, 2)
+    s = check_case(Sampler, means, con, values, scrambled, orders=(0, 1, 2), gtol="bound")
+    assert lattice_of(s, hip_lib) == (0, 0)
+    # columns in no order inside every row: the first descent comes early, no candidate at all
+    cols = g[:, rng.permutation(64)].reshape(-1, 2)
+    s = check_case(Sampler, means, con, values, cols, orders=(0, 1, 2), gtol="bound")
+    assert lattice_of(s, hip_lib) == (0, 0)
+
+
+def test_jittered_lattice_and_nonfinite_points(Sampler, hip_lib):
+    rng = np.random.default_rng(13)
+    means, con, values = random_gaussians(rng, 500, 1, log_sigma_mean=-2.6, log_sigma_std=0.4)
+    g = grid(64, 48, lo=(-1, -1), hi=(1, 1))
+    step = np.array([2 / 63, 2 / 47])
+    jit = g + rng.uniform(-0.3, 0.3, g.shape) * step        # rows stay monotone in x: still a lattice in row order
+    s = check_case(Sampler, means, con, values, jit, orders=(0, 1, 2), gtol="bound")
+    assert lattice_of(s, hip_lib) == (64, 48)
+    # a NaN point: the index tiles are "not compact", the sort takes over; the NaN point's outputs are NaN,
+    # every other point's the oracle's
+    bad = g.copy()
+    bad[1000] = np.nan
+    t = [dev32(a) for a in (means, values, con, bad)]
+    s = Sampler(True, backend="binned")
+    s.preprocess(t[0], t[1], None, t[2], t[3])
+    u = s.sample_gaussians()
+    assert lattice_of(s, hip_lib) == (0, 0)
+    d = Sampler(True, backend="dense")
+    d.preprocess(t[0], t[1], None, t[2], t[3])
+    ud = d.sample_gaussians()
+    keep = np.arange(g.shape[0]) != 1000
+    assert rel(u[keep], ud[keep]) < 1e-5
+
+
+def test_index_tiled_samples_are_reused_and_survive_new_gaussians(Sampler, hip_lib):
+    """The reference's roll-out (main_pn.py:317-324): new Gaussians on the same grid every step -- the index-tiled
+    samples half is built once and shared."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(17)
+    pts = dev32(grid(96, 64))
+    s = Sampler(False, backend="binned", fuse="all")
+    first = None
+    for step in range(3):
+        means, con, values = random_gaussians(rng, 700, 1, log_sigma_mean=-2.8, log_sigma_std=0.4)
+        t = [dev32(a) for a in (means, values, con)]
+        s.preprocess(t[0], t[1], None, t[2], pts)
+        if first is None:
+            first = s._plan.samples
+        assert s._plan.samples is first and lattice_of(s, hip_lib) == (96, 64)
+        outs = s.sample((0, 1, 2))
+        exp = c_oracle.forward(means, con, values, pts.cpu().double().numpy(), orders=(0, 1, 2))
+        for o in range(3):
+            assert rel(outs[o], exp[o]) < 1e-5
+
+
+def test_bench_grid_is_index_tiled_and_equals_the_sorted_build(Sampler, hip_lib):
+    """C3's own points (1024^2 grid, 65 536 lattice Gaussians, kappa 0.5): index-tiled and sorted builds evaluate
+    the same pairs up to the order inside a tile; a slice against the oracle."""
+    from oracle import c_oracle
+    from pigs_amd import synthetic
+    gs = synthetic.lattice_gaussians(256, 256, 0.5, seed=0)
+    pts = synthetic.grid_samples(1024).float().cuda()
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    outs = {}
+    for mode in (None, "0"):
+        with lattice_env(mode):
+            s = Sampler(False, backend="binned", fuse="all")
+            with torch.no_grad():
+                s.preprocess(t["means"], t["values"], None, t["conics"], pts)
+                outs[mode] = [o.clone() for o in s.sample((0, 1, 2))]
+            assert lattice_of(s, hip_lib) == ((1024, 1024) if mode is None else (0, 0))
+    for a, b in zip(outs[None], outs["0"]):
+        assert rel(a, b) < 2e-6
+    idx = torch.arange(0, pts.shape[0], 509, device="cuda")[:2048]
+    args = [gs[k].float().double().numpy() for k in ("means", "conics", "values")]
+    exp = c_oracle.forward(*args, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
+    for o in range(3):
+        assert rel(outs[None][o][idx], exp[o]) < 1e-5

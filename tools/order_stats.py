@@ -21,7 +21,7 @@ for case in sys.argv[1].split(","):
         pts = pts[torch.randperm(pts.shape[0], generator=g)]
     else:
         pts = (torch.randn((1 << 20, 2), generator=g) * float(case.split(":")[1])).clamp(-1, 1)
-    s = GaussianSampler(False, fuse="all", backend="binned", host="ctypes")
+    s = GaussianSampler(False, fuse="all", backend="binned", host="ctypes", defer_lists=False)
     with torch.no_grad():
         s.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts.cuda())
     print(case, list_stats(s._plan), flush=True)

@@ -17,7 +17,7 @@ elif case == "random":
 else:
     sigma = float(case.split(":")[1]) if ":" in case else 0.15
     pts = (torch.randn((1 << 20, 2), generator=g) * sigma).clamp(-1, 1)
-s = GaussianSampler(False, backend="binned")
+s = GaussianSampler(False, backend="binned", defer_lists=False)
 with torch.no_grad():
     s.preprocess(t["means"], t["values"], None, t["conics"], pts.cuda())
 plan = s._plan
