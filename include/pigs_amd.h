@@ -220,11 +220,15 @@ size_t pigs_plan_error_offset(void);
  * non-zero when the points were taken in INDEX-TILED order -- they arrived as an rf x rs lattice in row order
  * (rf points along the fastest axis; both multiples of 8: meshgrid(indexing="xy").reshape(-1, 2),
  * test_gaussian_sampling.py:43-46, main_pn.py:317-324), so a point's tile (an 8 x 8 index patch) and group (4 x 4)
- * are index arithmetic and the build neither keys, counts, scans nor scatters the points (its first launch writes
- * them in tile order) -- and {0, 0} when they were sorted into cells.  The decision is the build's own, on the
- * device (the first descent of a coordinate gives rf; every index tile must be at most twice as wide and as tall
- * as its share of the bounding box); results never depend on it, PIGS_LATTICE=0 in the environment switches it
- * off.  Introspection for tools and tests. */
+ * are index arithmetic: the build neither keys, counts, scans, scatters NOR COPIES the points -- and {0, 0} when
+ * they were sorted into cells.  The decision is the build's own, on the device (the first backward step of the
+ * fastest coordinate gives rf; the largest steps between index neighbours along and across rows bound every index
+ * tile, which must stay within twice its share of the bounding box); results never depend on it, PIGS_LATTICE=0 in
+ * the environment switches it off.
+ * CONTRACT that comes with it: a samples workspace in index-tiled order holds the ADDRESS of `samples`, not the
+ * points; pigs_plan_build / pigs_plan_forward / pigs_plan_backward / pigs_residual_* read the caller's array
+ * through it.  `samples` must therefore stay allocated and unmodified for as long as the samples workspace is
+ * used (the sorted order has no such requirement; a caller that cannot promise it sets PIGS_LATTICE=0). */
 size_t pigs_samples_lattice_offset(void);
 
 /* Introspection for tools and tests (never needed to use a plan): where the tile lists sit inside a

@@ -121,17 +121,22 @@ struct SampleParams {
     uint32_t order_stat[2];
     // INDEX-TILED ("lattice") order (round 4).  A point set that arrives as an rf x rs lattice in row order (rf
     // points along the fast axis, both multiples of 8: meshgrid(indexing="xy").reshape(-1, 2),
-    // test_gaussian_sampling.py:43-46, main_pn.py:317-324) needs no sort: its tile of a point is index
+    // test_gaussian_sampling.py:43-46, main_pn.py:317-324) needs no sort and no copy: its tile of a point is index
     // arithmetic (lattice_tile_xy / lattice_index below: tile = an 8 x 8 index patch, group = a 4 x 4 patch,
-    // tiles in serpentine pair-rows so that 4 consecutive tiles from a multiple of 4 are a compact block), and the
-    // first build launch writes `spts` in that order itself -- no cell keys, no counters, no scan, no scatter of the
-    // points.  Correctness never depends on the points BEING a lattice (the lists are built from the groups' real
-    // bounding boxes): the detection (first descent of a coordinate = the row length; every index tile no wider
-    // than twice its share of the bounding box) only decides which order is compact.
+    // tiles in serpentine pair-rows so that 4 consecutive tiles from a multiple of 4 are a compact block) and the
+    // sampling kernels read the caller's array through it (tile_point) -- no cell keys, no counters, no scan, no
+    // scatter, no `spts`.  Correctness never depends on the points BEING a lattice (the lists are built from the
+    // groups' real bounding boxes): the detection (the first backward step of the fast coordinate = the row length;
+    // the largest steps between index neighbours along and across rows bound every index tile's extent, which must
+    // stay within twice its share of the bounding box) only decides which order is compact.
     // lat_cand: {candidate rf, fast axis (0: x, 1: y)} from the first launch; lat: {rf, rs} when the points are
     // index-tiled, {0, 0} when they were sorted into cells.
     uint32_t lat_cand[2];
     uint32_t lat[2];
+    // index-tiled order: the CALLER's sample array (device address).  The samples workspace then holds no copy of the
+    // points -- the sampling kernels read them where the caller keeps them, through the index arithmetic -- so the
+    // array must stay valid and unmodified for as long as the workspace is used (the hosts keep the tensor).
+    uint64_t src;
 };
 
 // ---- index-tiled order: position in `spts` <-> index in the caller's array -------------------
@@ -220,7 +225,7 @@ inline SamplesLayout make_samples_layout(int64_t M) {
     size_t o = 0;
     p.off_params = o;   o = align_up(o + sizeof(SampleParams), 256);
     p.off_boxes = o;    o = align_up(o + sizeof(float4) * PLAN_BBOX_BLOCKS, 256);
-    p.off_lat = o;      o = align_up(o + sizeof(float2) * PLAN_BBOX_BLOCKS, 256);   // per-workgroup {widest, tallest} index tile
+    p.off_lat = o;      o = align_up(o + sizeof(float4) * PLAN_BBOX_BLOCKS, 256);   // per-workgroup largest neighbour steps (index-tiled order)
     // counters and the scan's per-workgroup aggregates are adjacent: zeroed together
     p.off_counts = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.scan_blocks * PLAN_SCAN_BLOCK, 256);
     p.off_agg = o;      o = align_up(o + sizeof(uint64_t) * (size_t)p.scan_blocks, 256);
@@ -305,7 +310,7 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_rec = o;      o = align_up(o + 32 * ((size_t)N + 1), 256);           // + the all-zero record N
     p.off_box = o;      o = align_up(o + 16 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
-    p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [8][N]
+    p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [N][8]
     p.off_hdr = o;      o = align_up(o + sizeof(uint32_t) * TILE_HDR_WORDS * (size_t)p.ntiles, 256);
     p.off_ptiles = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles, 256);           // queue of the TILE_MODE_POINTS tiles
     p.off_tlist = o;    o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles * p.list_cap, 256);
@@ -320,9 +325,39 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
 // Device view of a samples workspace.
 struct SamplesView {
     const SampleParams* params;
-    const SPoint* spts;           // sorted points: coordinates + original index
+    const SPoint* spts;           // sorted points: coordinates + original index (not in index-tiled order)
     uint32_t M, ntiles;
 };
+
+// How the points of a samples workspace are ordered, read once per wave (wave-uniform).
+struct PointOrder {
+    const float2* src;            // index-tiled: the caller's array
+    uint32_t rf, ntx, nty;        // rf == 0: sorted into cells (SamplesView::spts)
+};
+__device__ inline PointOrder point_order(const SamplesView& sv) {
+    PointOrder po;
+    po.rf = sv.params->lat[0];
+    const uint32_t rs = sv.params->lat[1];
+    po.ntx = po.rf >> 3;
+    po.nty = rs >> 3;
+    po.src = (const float2*)(uintptr_t)sv.params->src;
+    return po;
+}
+// the point at position `lane` of tile `tile` (tile wave-uniform in the tile kernels: its (tx, ty) stay scalar); a
+// position behind the last point repeats the last one (never stored)
+__device__ inline SPoint tile_point(const SamplesView& sv, const PointOrder& po, uint32_t tile, uint32_t lane) {
+    if (po.rf != 0u) {            // M is a multiple of 64 here: every position holds a point
+        uint32_t tx, ty;
+        lattice_tile_xy(tile, po.ntx, po.nty, tx, ty);
+        SPoint sp;
+        sp.m = lattice_index(tx, ty, lane, po.rf);
+        const float2 p = po.src[sp.m];
+        sp.x = p.x; sp.y = p.y;
+        return sp;
+    }
+    const uint32_t m = tile * TILE_POINTS + lane;
+    return sv.spts[m < sv.M ? m : sv.M - 1];
+}
 
 // Device view of a plan workspace: raw pointers + the scalars kernels need.
 struct PlanView {
@@ -339,7 +374,7 @@ struct PlanView {
     int G0, L;
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     float q_max;                  // list build only: the WIDE cut-off max(q_f, q_b) (the sampling kernels read params->q_f / q_b)
-    float* gacc;                  // backward scratch: [8][N] sorted-order gradient sums
+    float* gacc;                  // backward scratch: [N][8] sorted-order gradient sums, one 32-byte row per Gaussian
     // Staging for points in no order (null: not in this launch).  A tile of such points sends its outputs to three
     // arrays through the points' original indices: three scattered 4 / 8 / 16-byte stores per point, each of which
     // costs the memory a whole 32-byte sector (96 MB written for 28 MB of outputs at 1 M points: forward 54 us where

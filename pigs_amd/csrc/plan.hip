@@ -65,8 +65,10 @@ struct BuildArgs {
     // samples side
     SampleParams* sparams;
     float4* sboxes;       // [PLAN_BBOX_BLOCKS] per-workgroup partial boxes {min x, min y, max x, max y}
-    float2* slat;         // [PLAN_BBOX_BLOCKS] per-workgroup {widest, tallest} index tile (index-tiled order, plan.h)
+    float4* slat;         // [PLAN_BBOX_BLOCKS] per-workgroup largest neighbour steps {along x, along y, across x, across y} (index-tiled order)
     int no_lattice;       // PIGS_LATTICE=0: never index-tiled (tests, A/B)
+    uint32_t rf_hint;     // the row length the last completed build of a point set of this size found (0: none): the first
+                          // launch loads its tiles for that length while it is still verifying it
     uint32_t* scounts;    // [s_scan_blocks * PLAN_SCAN_BLOCK] fine-cell counters, followed by the scan aggregates
     unsigned long long* sagg;
     uint32_t* sstarts;
@@ -142,17 +144,24 @@ __device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, flo
 
 // Launch 1 of a samples build (PLAN_BBOX_BLOCKS workgroups of 1 024 threads): zero the cell counters (of the
 // plan too, when one is built alongside); per-workgroup bounding box of the sample points, written as a plain
-// partial.  And the INDEX-TILED order (plan.h, SampleParams::lat): every workgroup finds the first index at which
-// a coordinate descends -- the row length rf of a lattice in row order (a search of the first 2 049 points, of
-// 16 385 when those hold none; all workgroups read the same few KB) -- and, when rf and M / rf are multiples of 8,
-// takes the points tile by tile instead of linearly: the wave writes the tile's 64 points to `spts` in tile order
-// (the sort's whole output for such a point set) and keeps the widest / tallest tile it met, from which the next
-// launch decides whether the index tiles are compact (and the sort is skipped) or the candidate was a coincidence
-// (and the sort overwrites `spts`).
+// partial.  And what the INDEX-TILED order (plan.h, SampleParams::lat) is decided from, in the same streaming pass:
+// every workgroup finds the first index at which the fast coordinate steps backwards -- the row length rf of a
+// lattice in row order (a search of the first 2 049 points, of 16 385 when those hold none; all workgroups read the
+// same few KB) -- and, for a row length whose rf and M / rf are multiples of 8, the largest steps between
+// neighbours: along a row (point i against i - 1, row ends left out) and across rows (point i against i - rf),
+// per coordinate.  An 8 x 8 index tile is at most 7 (along + across) wide and high: the next launch holds that
+// against the bounding box and decides whether index tiles are compact -- then nothing is sorted and NOTHING IS
+// COPIED: the sampling kernels read the caller's array through the index arithmetic -- or the points go through
+// the sort.  The pass runs on the row length of the last build of this size (the library's memory, `rf_hint`)
+// while the search is still in flight, and is repeated only when the search finds another one.
 constexpr uint32_t BBOX_THREADS = 1024;
 constexpr uint32_t LAT_SEARCH0 = 2048, LAT_SEARCH1 = 16384;
+__device__ __forceinline__ bool lattice_shape_ok(uint32_t rf, uint32_t n) {
+    const uint32_t rs = rf ? n / rf : 0u;
+    return rf >= 8u && (rf & 7u) == 0u && rs * rf == n && (rs & 7u) == 0u && n >= 64u;
+}
 __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
-    __shared__ float sh[16][6];
+    __shared__ float sh[16][8];
     __shared__ uint32_t shk[16];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -170,7 +179,55 @@ __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
         if (fabsf(y) < INF) { y0 = fminf(y0, y); y1 = fmaxf(y1, y); }
     };
     const float2* pts = (const float2*)a.samples;
+    const float4* pts2 = (const float4*)a.samples;
     const uint32_t n = a.M;
+    const uint32_t npair = n / 2;                 // float4 = two points
+    const uint32_t stride = gridDim.x * BBOX_THREADS;
+    // the largest neighbour steps (NaN / inf coordinates: +inf, never compact)
+    float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+    auto step = [&](float& s, float u, float v) {
+        const float d = fabsf(u - v);
+        s = d == d ? fmaxf(s, d) : INF;
+    };
+    // one streaming pass: the box (first time only) and, with a row length, the neighbour steps
+    auto pass = [&](uint32_t rf, bool box) {
+        ax = ay = bx = by = 0.f;
+        const uint32_t half = rf >> 1;            // rf is even: a float4 never straddles a row end
+        uint32_t i = blockIdx.x * BBOX_THREADS + tid;
+        uint32_t w = rf ? (2u * i + 2u) % rf : 1u;                     // (index of the point behind pair j) mod rf; 0: a row starts there
+        const uint32_t ds = rf ? (2u * stride) % rf : 0u;              // its step from pair j to pair j + stride
+        for (; i < npair; i += 4 * stride) {
+            float4 v[4], up[4];
+            float2 nx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = i + k * stride;
+                const uint32_t jj = j < npair ? j : i;
+                v[k] = pts2[jj];
+                if (rf) {
+                    nx[k] = pts[2u * jj + 2u < n ? 2u * jj + 2u : 2u * jj + 1u];
+                    up[k] = pts2[jj >= half ? jj - half : jj];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = i + k * stride;
+                if (j >= npair) break;
+                if (box) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
+                if (rf) {
+                    step(ax, v[k].z, v[k].x); step(ay, v[k].w, v[k].y);
+                    if (w != 0u && 2u * j + 2u < n) { step(ax, nx[k].x, v[k].z); step(ay, nx[k].y, v[k].w); }
+                    if (j >= half) {
+                        step(bx, v[k].x, up[k].x); step(by, v[k].y, up[k].y);
+                        step(bx, v[k].z, up[k].z); step(by, v[k].w, up[k].w);
+                    }
+                    w += ds;
+                    if (w >= rf) w -= rf;
+                }
+            }
+        }
+        if (box && (n & 1u) && blockIdx.x == 0 && tid == 0) take(pts[n - 1].x, pts[n - 1].y);
+    };
     // ---- the candidate row length.  The fast axis is the one along which the first two points differ most, its
     // direction the sign of that step; a row ends where the fast coordinate steps the other way (a jittered lattice
     // keeps its rows as long as the jitter stays below half a step).  key = that first index (NONE: none found).
@@ -198,9 +255,13 @@ __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
         for (int w = 1; w < 16; ++w) r = min(r, shk[w]);
         return r;
     };
-    uint32_t key = NONE;
-    if (!a.no_lattice && n >= 64u) {
-        key = block_min(min(probe(tid), probe(tid + 1024u)));
+    const bool search = !a.no_lattice && n >= 64u;
+    uint32_t key = search ? min(probe(tid), probe(tid + 1024u)) : NONE;
+    // the pass on the remembered row length (or, without one, for the box alone), the search's loads in flight beside it
+    const uint32_t hf = search && lattice_shape_ok(a.rf_hint, n) ? a.rf_hint : 0u;
+    pass(hf, true);
+    if (search) {
+        key = block_min(key);
         if (key == NONE && n > LAT_SEARCH0 + 1u) {
             uint32_t k2 = NONE;
 #pragma unroll 2
@@ -209,72 +270,26 @@ __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
         }
     }
     const uint32_t rf = key == NONE ? 0u : key + 1u;
-    const uint32_t rs = rf ? n / rf : 0u;
-    const bool cand = rf >= 8u && (rf & 7u) == 0u && rs * rf == n && (rs & 7u) == 0u;      // block-uniform
+    const bool cand = lattice_shape_ok(rf, n);      // block-uniform
+    if (cand && rf != hf) pass(rf, false);          // first build of a size, or the points changed shape
     if (blockIdx.x == 0 && tid == 0) {
         a.sparams->lat_cand[0] = cand ? rf : 0u;
         a.sparams->lat_cand[1] = axis;
     }
-    float wmax = 0.f, hmax = 0.f;              // widest / tallest index tile this wave met (wave-uniform)
-    if (cand) {
-        const uint32_t ntx = rf >> 3, nty = rs >> 3, ntiles = ntx * nty;
-        const uint32_t gw = blockIdx.x * 16u + (uint32_t)wave, nw = gridDim.x * 16u;
-        for (uint32_t t0 = gw; t0 < ntiles; t0 += 4u * nw) {
-            float2 p[4];
-            uint32_t m[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t t = t0 + (uint32_t)k * nw;
-                uint32_t tx = 0, ty = 0;
-                lattice_tile_xy(t < ntiles ? t : t0, ntx, nty, tx, ty);
-                m[k] = lattice_index(tx, ty, (uint32_t)lane, rf);
-                p[k] = pts[m[k]];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t t = t0 + (uint32_t)k * nw;
-                if (t >= ntiles) break;                 // wave-uniform
-                take(p[k].x, p[k].y);
-                float bx0 = p[k].x, bx1 = p[k].x, by0 = p[k].y, by1 = p[k].y;
-                row_box_dpp(bx0, bx1, by0, by1);
-                wave_box_from_rows_dpp(bx0, bx1, by0, by1);
-                const float w = bx1 - bx0, h = by1 - by0;      // NaN / inf coordinates: never compact
-                wmax = w == w ? fmaxf(wmax, w) : INF;
-                hmax = h == h ? fmaxf(hmax, h) : INF;
-                SPoint sp;
-                sp.x = p[k].x; sp.y = p[k].y; sp.m = m[k];
-                a.spts[(size_t)t * TILE_POINTS + (uint32_t)lane] = sp;
-            }
-        }
-    } else {
-        const float4* pts2 = (const float4*)a.samples;
-        const uint32_t npair = n / 2;                 // float4 = two points
-        const uint32_t stride = gridDim.x * BBOX_THREADS;
-        for (uint32_t i = blockIdx.x * BBOX_THREADS + tid; i < npair; i += 4 * stride) {
-            float4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t j = i + k * stride;
-                v[k] = pts2[j < npair ? j : i];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
-        }
-        if ((n & 1u) && blockIdx.x == 0 && tid == 0) take(pts[n - 1].x, pts[n - 1].y);
-    }
     x0 = wave_min_bcast(x0); y0 = wave_min_bcast(y0);
     x1 = wave_max_bcast(x1); y1 = wave_max_bcast(y1);
+    ax = wave_max_bcast(ax); ay = wave_max_bcast(ay); bx = wave_max_bcast(bx); by = wave_max_bcast(by);
     __syncthreads();
-    if (lane == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; sh[wave][4] = wmax; sh[wave][5] = hmax; }
+    if (lane == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; sh[wave][4] = ax; sh[wave][5] = ay; sh[wave][6] = bx; sh[wave][7] = by; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 16; ++w) {
             x0 = fminf(x0, sh[w][0]); y0 = fminf(y0, sh[w][1]);
             x1 = fmaxf(x1, sh[w][2]); y1 = fmaxf(y1, sh[w][3]);
-            wmax = fmaxf(wmax, sh[w][4]); hmax = fmaxf(hmax, sh[w][5]);
+            ax = fmaxf(ax, sh[w][4]); ay = fmaxf(ay, sh[w][5]); bx = fmaxf(bx, sh[w][6]); by = fmaxf(by, sh[w][7]);
         }
         a.sboxes[blockIdx.x] = make_float4(x0, y0, x1, y1);
-        a.slat[blockIdx.x] = make_float2(wmax, hmax);
+        a.slat[blockIdx.x] = make_float4(ax, ay, bx, by);
     }
 }
 
@@ -287,36 +302,36 @@ __global__ __launch_bounds__(256) void plan_zero_kernel(BuildArgs a) {
 }
 
 // every workgroup of the count kernel reduces the PLAN_BBOX_BLOCKS partials (4 KB, L2 resident)
-// sbox[0..3] = the box; sbox[4], sbox[5] = the widest / tallest index tile (meaningful when the first launch had a
-// lattice candidate; a NaN partial cannot occur: the first launch turns it into +inf)
-__device__ __forceinline__ void reduce_boxes(const float4* boxes, const float2* lat, float* sbox, float (*sh)[6]) {
+// sbox[0..3] = the box; sbox[4..7] = the largest neighbour steps {along x, along y, across x, across y} (meaningful
+// when the first launch had a lattice candidate; a NaN partial cannot occur: the first launch turns it into +inf)
+__device__ __forceinline__ void reduce_boxes(const float4* boxes, const float4* lat, float* sbox, float (*sh)[8]) {
     static_assert(PLAN_BBOX_BLOCKS == 256, "one partial per thread");
     const float4 p = boxes[threadIdx.x];
-    const float2 l = lat[threadIdx.x];
-    float v[6] = {p.x, p.y, p.z, p.w, l.x, l.y};
+    const float4 l = lat[threadIdx.x];
+    float v[8] = {p.x, p.y, p.z, p.w, l.x, l.y, l.z, l.w};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = (k & 2) || k >= 4 ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
+    for (int k = 0; k < 8; ++k) v[k] = (k & 2) || k >= 4 ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sh[wave][k] = v[k];
+        for (int k = 0; k < 8; ++k) sh[wave][k] = v[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 8; ++k) {
         float r = sh[0][k];
         for (int w = 1; w < 4; ++w) r = (k & 2) || k >= 4 ? fmaxf(r, sh[w][k]) : fminf(r, sh[w][k]);
         sbox[k] = r;
     }
 }
-// the decision behind a lattice candidate (plan.h, SampleParams::lat): every index tile at most twice as wide and
-// as tall as its share of the bounding box (an exact lattice: 7/8 of it).  Uniform over the launch: every workgroup
-// reduces the same partials.
+// the decision behind a lattice candidate (plan.h, SampleParams::lat): an 8 x 8 index tile is at most 7 (along +
+// across) steps wide and high; it must be at most twice as wide and as high as its share of the bounding box (an
+// exact lattice: 7/8 of it).  Uniform over the launch: every workgroup reduces the same partials.
 __device__ __forceinline__ bool lattice_compact(const float* sbox, uint32_t rf, uint32_t rs, uint32_t axis) {
     if (rf == 0u) return false;
     const float ex = sbox[2] - sbox[0], ey = sbox[3] - sbox[1];
     const float nx = (float)(axis ? rs : rf), ny = (float)(axis ? rf : rs);      // points along x / along y
-    return sbox[4] * nx <= 16.f * ex && sbox[5] * ny <= 16.f * ey;              // NaN / inf: false
+    return 7.f * (sbox[4] + sbox[6]) * nx <= 16.f * ex && 7.f * (sbox[5] + sbox[7]) * ny <= 16.f * ey;      // NaN / inf: false
 }
 
 // Launch 2: cell key of every Gaussian / point and its rank inside the cell, with ONE returning
@@ -342,7 +357,7 @@ __device__ __forceinline__ Run run_of(uint32_t k, int lane) {
 __device__ __forceinline__ void samples_hist_part(const BuildArgs& a, uint32_t w, const SampleGrid& sg, uint32_t* lh, int lane);
 
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
-    __shared__ float shb[4][6];
+    __shared__ float shb[4][8];
     __shared__ uint32_t lh[SAMPLES_COARSE_BINS];
     const int lane = threadIdx.x & 63;
     // Every dependent memory round trip costs 2-4 us in this kernel (in-kernel stamps): issue the
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     } else if (!a.coarse && lat_rf == 0u) {
         load_points();
     }
-    float sbox[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sbox[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool lattice = false;
     if (a.do_samples) {
         reduce_boxes(a.sboxes, a.slat, sbox, shb);
@@ -390,6 +405,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             a.sparams->scan_error = 0;
             a.sparams->lat[0] = lattice ? lat_rf : 0u;
             a.sparams->lat[1] = lattice ? a.M / lat_rf : 0u;
+            a.sparams->src = lattice ? (uint64_t)(uintptr_t)a.samples : 0ull;
         }
         if (a.do_plan) {
             a.params->gg = g;
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         base = __shfl(base, r.start);
         if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
     } else if (lattice) {
-        // index-tiled: the first launch has written `spts`; no keys, no counters (block-uniform)
+        // index-tiled: nothing to key, count or move (block-uniform)
     } else if (a.coarse) {
         samples_hist_part(a, blockIdx.x - gblocks, sg, lh, lane);
     } else {
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         // build into this workspace (PIGS_BUILD_PLAN_WS_CLEAN) needs no zeroing launch
         for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.zero_words; k += gridDim.x * 256) a.counts[k] = 0u;
     }
-    if (!gpart && a.sparams->lat[0] != 0u) return;     // index-tiled points: `spts` is the first launch's (block-uniform)
+    if (!gpart && a.sparams->lat[0] != 0u) return;     // index-tiled points: nothing to move (block-uniform)
     if (!gpart && a.coarse && a.h_chunk <= SCATTER_STAGE_MAX) {
         // (the sample workgroups of this launch are then the chunks' workgroups: h_wgs of them)
         uint32_t* words = (uint32_t*)(scatter_stage + a.h_chunk);
@@ -1038,12 +1054,13 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
     const float INF = __builtin_huge_valf();
     SPoint sp[LISTS_TPW];
     bool valid[LISTS_TPW];
+    const PointOrder po = point_order(a.sv);
 #pragma unroll
     for (int t = 0; t < LISTS_TPW; ++t) {
         const uint32_t m = (tile0 + (uint32_t)t) * TILE_POINTS + (uint32_t)lane;
         valid[t] = m < a.sv.M;           // also false for every point of a tile behind the last one
         sp[t] = SPoint{0.f, 0.f, 0u};
-        if (valid[t]) sp[t] = a.sv.spts[m];
+        if (tile0 + (uint32_t)t < ntiles) sp[t] = tile_point(a.sv, po, tile0 + (uint32_t)t, (uint32_t)lane);     // wave-uniform
     }
     float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
 #pragma unroll
@@ -1593,7 +1610,7 @@ __device__ __forceinline__ void forward_points_quad(const PlanView& pv, const Sa
     const int row = lane >> 4, i = lane & 15;
     const uint32_t m = tile * TILE_POINTS + quad * 4u + (uint32_t)row;
     const bool valid = m < sv.M;
-    const SPoint sp = sv.spts[valid ? m : sv.M - 1];
+    const SPoint sp = tile_point(sv, point_order(sv), tile, quad * 4u + (uint32_t)row);
     const float s[2] = {sp.x, sp.y};
     float acc[L::N];
 #pragma unroll
@@ -1628,7 +1645,7 @@ __device__ __forceinline__ void forward_tile(const PlanView& pv, const SamplesVi
     char* const qbase = (char*)lds.rec;
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
     const bool valid = m < sv.M;
-    const SPoint sp = sv.spts[valid ? m : sv.M - 1];      // lanes behind the last point repeat it (never stored)
+    const SPoint sp = tile_point(sv, point_order(sv), tile, (uint32_t)lane);      // lanes behind the last point repeat it (never stored)
     const float s[2] = {sp.x, sp.y};
     float acc[L::N];
 #pragma unroll
@@ -2009,7 +2026,7 @@ __device__ __forceinline__ void load_tile_point(const SamplesView& sv, uint32_t 
                                                 const float4* __restrict__ stage = nullptr) {
     const uint32_t m = tile * TILE_POINTS + (uint32_t)lane;
     valid = m < sv.M;
-    sp = sv.spts[valid ? m : sv.M - 1];
+    sp = tile_point(sv, point_order(sv), tile, (uint32_t)lane);
     if constexpr (C == 1 && (MASK == 7 || MASK == 19)) {
         if (stage) {        // the incoming gradients of this point as one record (gradients_to_stage_kernel)
             const float4 a = stage[2 * (size_t)sp.m];
@@ -2036,6 +2053,41 @@ __device__ __forceinline__ void load_tile_point(const SamplesView& sv, uint32_t 
     }
 }
 
+// The end of a step: every entry's rows of the sums table are added up and leave as atomics into gacc[j][8] (one
+// 32-byte row per sorted Gaussian).  Float atomics execute at the memory side, one request per 64-byte segment an
+// instruction touches (MI355X_MICROARCH.md, Global float atomics: full rate for 256 contiguous bytes, lanes in
+// different rows up to 17x slower), and the entries of a step come in runs of consecutive sorted indices (the list
+// build walks contiguous record ranges).  So an instruction takes EIGHT consecutive entries, lane = (entry, value):
+// eight 32-byte rows, mostly adjacent -- ~2.4x fewer segment requests than one instruction per value over all the
+// entries of the step (which touched every run once per value: round 3, gacc[8][N]).  A lane fetches its entry's
+// masks and table positions (packed into one word by the entry's lane) and its index with two lane shuffles.
+template <int NV>
+__device__ __forceinline__ void flush_step(const PlanView& pv, const TileLdsBwd<NV>& lds, uint32_t gm, uint32_t idx, const int* rank, int lane) {
+    constexpr int S = TileLdsBwd<NV>::S;
+    static_assert(BWD_STEP + 4 <= 128, "7 bits per table position");
+    uint32_t pk = gm & 15u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pk |= ((uint32_t)rank[g] & 127u) << (4 + 7 * g);
+    const uint64_t live = __ballot((pk & 15u) != 0u);
+    const int q = lane & 7, sub = lane >> 3;
+    const int qs = q < S ? q : 0;
+#pragma unroll 2
+    for (int j = 0; j < BWD_STEP / 8; ++j) {
+        if (((live >> (8 * j)) & 0xffull) == 0ull) continue;           // wave-uniform: none of these eight entries reaches the tile
+        const int e = 8 * j + sub;
+        const uint32_t pe = (uint32_t)__shfl((int)pk, e), ie = (uint32_t)__shfl((int)idx, e);
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (pe >> g & 1u) v += lds.sums[g][(pe >> (4 + 7 * g)) & 127u][qs];
+#ifndef PIGS_BWD_PROBE_NO_ATOMICS
+        if ((pe & 15u) != 0u && q < NV) atomicAdd(&pv.gacc[(size_t)ie * 8 + q], v);
+#else
+        if (v == 1.2345e-30f) pv.gacc[(size_t)ie * 8 + q] = v;      // keeps the sums alive, never stores
+#endif
+    }
+}
+
 // one tile through its own lists (tile list / group lists / record ranges)
 template <int C, int MASK>
 __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesView& sv, uint32_t tile,
@@ -2045,7 +2097,6 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
     constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;      // a residual's backward = orders 0, 1, trace
     using BL = BwdLayout<2, C>;
     constexpr int NV = BL::N;
-    constexpr int S = TileLdsBwd<NV>::S;
     SPoint sp;
     bool valid;
     Gsym<float, 2, C, EM> G;
@@ -2093,28 +2144,7 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
         backward_rows<C, EM>(s, G, lds, rows, lane);
 #endif
         wave_lds_fence();
-        if (have && gm != 0u) {               // this lane's entry: its rows of the table, one atomic per value
-            float sum[S];
-#pragma unroll
-            for (int q = 0; q < S; ++q) sum[q] = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (gm >> g & 1u) {
-                    const float2* src = (const float2*)lds.sums[g][rank[g]];
-#pragma unroll
-                    for (int q = 0; q < S; q += 2) {
-                        const float2 v = src[q / 2];
-                        sum[q] += v.x; sum[q + 1] += v.y;
-                    }
-                }
-            }
-#ifndef PIGS_BWD_PROBE_NO_ATOMICS
-#pragma unroll
-            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], sum[q]);
-#else
-            if (sum[0] == 1.2345e-30f) pv.gacc[idx] = sum[1] + sum[2] + sum[3] + sum[4] + sum[5];      // keeps the sums alive, never stores
-#endif
-        }
+        flush_step<NV>(pv, lds, have ? gm : 0u, idx, rank, lane);
     }, ranges_mask);
 }
 
@@ -2136,7 +2166,7 @@ __device__ __forceinline__ void backward_points_helper(const PlanView& pv, const
     for (uint32_t qd = hw; qd < n * 16u; qd += nhw) {
         const uint32_t m = pv.ptiles[qd >> 4] * TILE_POINTS + (qd & 15u) * 4u + (uint32_t)row;
         const bool valid = m < sv.M;
-        const SPoint sp = sv.spts[valid ? m : sv.M - 1];
+        const SPoint sp = tile_point(sv, point_order(sv), pv.ptiles[qd >> 4], (qd & 15u) * 4u + (uint32_t)row);
         const float s[2] = {sp.x, sp.y};
         Gsym<float, 2, C, EM> G;
         if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
@@ -2150,7 +2180,7 @@ __device__ __forceinline__ void backward_points_helper(const PlanView& pv, const
                 for (int q = 0; q < NV; ++q) part[q] = 0.f;
                 bwd_accumulate<float, 2, C, EM, (EM & ORD3) != 0, C == 1>(part, s, r.mu, r.con, r.v, G);
 #pragma unroll
-                for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + j], part[q]);
+                for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)j * 8 + q], part[q]);
             }
         });
     }
@@ -2281,7 +2311,7 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void block_backward_ke
         }
         if (have && any != 0u) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)q * pv.N + idx], sum[q]);
+            for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)idx * 8 + q], sum[q]);
         }
     }
 }
@@ -2294,11 +2324,13 @@ __global__ __launch_bounds__(256) void plan_unpermute_kernel(PlanView pv, float*
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= pv.N) return;
     const uint32_t n = pv.g2o[j];
-    float v[BL::N];
-#pragma unroll
-    for (int k = 0; k < BL::N; ++k) {
-        v[k] = pv.gacc[(size_t)k * pv.N + j];
-        pv.gacc[(size_t)k * pv.N + j] = 0.f;       // leave the scratch zeroed for the next backward
+    float v[8];
+    {
+        float4* row = (float4*)(pv.gacc + (size_t)j * 8);
+        const float4 lo = row[0], hi = row[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f);      // leave the scratch zeroed for the next backward
+        row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (C == 1) {
         // the backward accumulates the factored sums (pair_math.h, FACTORED): finish them with the
@@ -2424,7 +2456,7 @@ static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, c
     char* b = (char*)sws;
     a.sparams = (SampleParams*)(b + s.off_params);
     a.sboxes = (float4*)(b + s.off_boxes);
-    a.slat = (float2*)(b + s.off_lat);
+    a.slat = (float4*)(b + s.off_lat);
     {
         const char* e = getenv("PIGS_LATTICE");
         a.no_lattice = e && e[0] == '0';
@@ -2479,7 +2511,8 @@ struct OrderHint {
     uint32_t builds = 0;           // samples builds of this (device, M) so far: the statistic is asked for after the first
                                    // two and after every 16th (the 8-byte copy is a 4 us blit in the build's stream)
     hipEvent_t ev = nullptr;
-    uint32_t* host = nullptr;      // pinned {runs, points}
+    uint32_t* host = nullptr;      // pinned {runs, points, lat_cand[2], lat[2]}: SampleParams from order_stat on
+    uint32_t rf = 0;               // the row length of the last completed build when it took the index-tiled order (else 0)
     uint64_t stamp = 0;
 };
 static std::mutex g_hint_mu;
@@ -2508,8 +2541,8 @@ static OrderHint* hint_entry(int device, int64_t M, bool create) {      // g_hin
         lru->ev = nullptr;
     }
     if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
-    if (!lru->host && hipHostMalloc((void**)&lru->host, 2 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
-    lru->device = device; lru->M = M; lru->coarse = false; lru->pending = false; lru->builds = 0; lru->stamp = ++g_hint_clock;
+    if (!lru->host && hipHostMalloc((void**)&lru->host, 6 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
+    lru->device = device; lru->M = M; lru->coarse = false; lru->pending = false; lru->builds = 0; lru->rf = 0; lru->stamp = ++g_hint_clock;
     return lru;
 }
 
@@ -2525,7 +2558,9 @@ static void hint_poll(OrderHint& h) {           // g_hint_mu held
     (void)hipGetLastError();          // hipErrorNotReady is an answer, not a failure
     if (q == hipSuccess) {
         h.pending = false;
-        if (h.host[1] > 0u) h.coarse = (uint64_t)h.host[0] * 100u > (uint64_t)h.host[1] * 55u;
+        h.rf = h.host[4];          // SampleParams::lat[0]
+        if (h.rf != 0u) h.coarse = false;      // index-tiled: the points arrived in order (and left no run statistic)
+        else if (h.host[1] > 0u) h.coarse = (uint64_t)h.host[0] * 100u > (uint64_t)h.host[1] * 55u;
     }
 }
 // order: 0 = ask the memory, 1 = one pass, 2 = coarse bins
@@ -2546,9 +2581,20 @@ static bool samples_take_coarse(const SamplesLayout& s, int order, hipStream_t s
     return h->coarse;
 }
 
+// the row length the last completed build of M points found (index-tiled order), or 0
+static uint32_t samples_rf_hint(const SamplesLayout& s, hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0u; }
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    OrderHint* h = hint_entry(dev, s.M, false);
+    if (!h) return 0u;
+    if (!stream_capturing(stream)) hint_poll(*h);
+    return h->rf;
+}
+
 // behind a samples build: ask for its {runs, points}
 static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t stream) {
-    if (s.M < COARSE_MIN_POINTS || s.cells_per_bin > SAMPLES_MAX_CELLS_PER_BIN || getenv("PIGS_SAMPLES_ORDER")) return;
+    if (s.M < 64) return;          // (the same record carries the lattice row length: wanted for every size)
     if (stream_capturing(stream)) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -2558,7 +2604,8 @@ static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t st
     const uint32_t nth = h->builds++;
     if (h->pending || (nth >= 2u && (nth & 15u) != 0u)) return;
     const SampleParams* sp = (const SampleParams*)((const char*)sws + s.off_params);
-    if (hipMemcpyAsync(h->host, sp->order_stat, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+    static_assert(offsetof(SampleParams, lat) == offsetof(SampleParams, order_stat) + 4 * sizeof(uint32_t), "one copy: order_stat, lat_cand, lat");
+    if (hipMemcpyAsync(h->host, sp->order_stat, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
         h->pending = true;
     (void)hipGetLastError();
@@ -2736,6 +2783,7 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     a.zero_gacc = !plan_ws_clean;
     const bool coarse = do_samples && samples_take_coarse(s, order, stream);
     fill_samples_args(a, s, sws, samples, coarse);
+    a.rf_hint = do_samples ? samples_rf_hint(s, stream) : 0u;
     PlanLayout p{};
     if (do_plan) {
         if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;

@@ -97,10 +97,12 @@ struct SamplePlan {
     at::Tensor workspace;
     int64_t M = 0;
     at::Tensor source;        // the caller's tensor (kept alive: its address cannot be handed to another tensor)
+    at::Tensor points;        // the contiguous array the build read: in index-tiled order (pigs_amd.h, ABI 7) the workspace
+                              // holds no copy of the points, the sampling kernels read THIS array
     uint32_t version = 0;     // its version counter at build time
     bool built = false;
 
-    SamplePlan(const at::Tensor& samples, const at::Tensor& src) : M(samples.size(0)), source(src) {
+    SamplePlan(const at::Tensor& samples, const at::Tensor& src) : M(samples.size(0)), source(src), points(samples) {
         const size_t nbytes = pigs_samples_workspace_bytes(M);
         if (nbytes == 0) throw PigsFailure("binned path does not support M=" + std::to_string(M));
         workspace = at::empty({(int64_t)nbytes}, samples.options().dtype(at::kByte));
@@ -609,7 +611,7 @@ struct Core {
     int fuse, backend;
     float q_max, q_max3, q_max_b;
     int reuse;
-    bool defer_lists = true;
+    bool defer_lists = false;         // PIGS_BUILD_DEFER_LISTS (measured: the one-launch lists + forward is not faster; an option)
     bool static_samples = false;      // a capture may reuse a remembered (eagerly built) SamplePlan: the caller promises
                                       // not to modify the samples tensor between replays (GraphedStep(static_samples=True))
     bool bound = false;

@@ -91,7 +91,7 @@ class SamplePlan:
     object serves every ``preprocess`` that is handed the same, unmodified samples tensor again --
     the reference's roll-out (main_pn.py:317-324) and any fixed collocation grid."""
 
-    __slots__ = ("workspace", "M", "source", "version", "built")
+    __slots__ = ("workspace", "M", "source", "points", "version", "built")
 
     def __init__(self, samples, source=None):
         lib = _lib.load()
@@ -105,6 +105,9 @@ class SamplePlan:
         # what this plan was built from: the caller's tensor (kept alive, so its address cannot be
         # handed to another tensor) and its version counter at build time
         self.source = source if source is not None else samples
+        # the contiguous array the build reads: in index-tiled order (include/pigs_amd.h, ABI 7) the workspace holds no
+        # copy of the points -- the sampling kernels read THIS array, so it lives as long as the workspace
+        self.points = samples
         self.version = self.source._version
         self.built = False
 
@@ -173,7 +176,7 @@ class Plan:
     BUILD_SAMPLES, WS_CLEAN, DEFER_LISTS = 1, 2, 32      # pigs_amd.h: PIGS_BUILD_SAMPLES, _PLAN_WS_CLEAN, _DEFER_LISTS
 
     def __init__(self, means, values, conics, samples, q_max, sample_plan=None, source=None, pool=None,
-                 recorded_only=False, q_max_backward=None, defer_lists=True):
+                 recorded_only=False, q_max_backward=None, defer_lists=False):
         lib = _lib.load()
         self.N, self.M, self.c, self.q_max = means.shape[0], samples.shape[0], values.shape[1], float(q_max)
         self.q_max_backward = max(self.q_max, float(q_max_backward if q_max_backward is not None else q_max))
@@ -492,10 +495,12 @@ class GaussianSampler:
     order asked for; ``"all"`` / ``"none"`` force either behaviour.  :meth:`sample` is the
     explicit fused entry point.
 
-    ``defer_lists`` (extension, keyword only; binned path; default True): ``preprocess`` stops in front of the tile
-    lists, and the first ``sample_*`` call builds them in the same launch as its own evaluation
-    (PIGS_BUILD_DEFER_LISTS, include/pigs_amd.h: the latency-bound list build hides behind the arithmetic, one kernel
-    boundary less); ``False`` builds them in ``preprocess`` (tools that read the lists without sampling).
+    ``defer_lists`` (extension, keyword only; binned path; default False): with True ``preprocess`` stops in front
+    of the tile lists and the first ``sample_*`` call builds them in the same launch as its own evaluation
+    (PIGS_BUILD_DEFER_LISTS, include/pigs_amd.h).  Built in round 4 to hide the latency-bound list build behind the
+    forward's arithmetic; measured at C3 it does not (49.8 us against 21.8 + 26.5 in two launches: every wave builds
+    first and evaluates afterwards, in step with all the others -- DESIGN.md section 3.3), so it is an option, not
+    the default.
 
     ``host`` (extension, keyword only): ``"native"`` (default; environment override PIGS_AMD_HOST) keeps
     the sampler's state and its autograd node in the C++ torch extension ``pigs_amd/_pigs_host.so``
@@ -519,7 +524,7 @@ class GaussianSampler:
 
     def __init__(self, flag=False, *, fuse="auto", backend="auto", q_max=36.0, q_max_order3=None,
                  q_max_backward=None, reuse_samples=True, unpinned_aggregate=False, aggregate_cap=None, host=None,
-                 defer_lists=True):
+                 defer_lists=False):
         if fuse not in ("auto", "all", "none"):
             raise ValueError("fuse must be 'auto', 'all' or 'none'")
         if backend not in ("auto", "dense", "binned"):

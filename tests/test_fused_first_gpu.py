@@ -10,9 +10,13 @@ import torch
 
 from oracle import c_oracle
 from pigs_amd import synthetic
-from test_binned_gpu import random_gaussians, rel, dev32
+from test_binned_gpu import random_gaussians, dev32, rel as _rel
 
 pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return _rel(a, b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else b)
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +62,7 @@ def test_first_forward_builds_the_lists_and_later_calls_read_them(Sampler, host,
     want = {0: exp[0], 1: exp[1], 2: exp[2], 3: exp[3], "lap": trace}
     for fused in (True, False):
         with env("PIGS_NO_FUSED_FIRST", None if fused else "1"):
-            s = Sampler(False, backend="binned", fuse="none", host=host)
+            s = Sampler(False, backend="binned", fuse="none", host=host, defer_lists=True)
             req = {k: t[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
             s.preprocess(req["means"], req["values"], None, req["conics"], pts)
             outs = s.sample(first)
@@ -82,7 +86,7 @@ def test_residual_and_backward_as_first_calls(Sampler, hip_lib):
     from pigs_amd import sampler as S
     t, pts, args = problem(1, seed=9)
     p64 = pts.cpu().double().numpy()
-    s = Sampler(False, backend="binned")
+    s = Sampler(False, backend="binned", defer_lists=True)
     s.preprocess(t["means"], t["values"], None, t["conics"], pts)
     r = s.residual(a0=0.7, a1=(0.2, -0.4), lap=-0.5)
     exp = c_oracle.forward(*args, p64, orders=(0, 1, 2))
@@ -114,7 +118,7 @@ def test_every_tile_mode_through_the_fused_launch(Sampler):
     cases.append(("ranges", m, con, v, rng.uniform(-0.5, 0.5, (3000, 2)), "ranges_tiles"))
     for name, m, con, v, pts, key in cases:
         t = [dev32(a) for a in (m, v, con, pts)]
-        s = Sampler(True, backend="binned")
+        s = Sampler(True, backend="binned", defer_lists=True)
         s.preprocess(t[0], t[1], None, t[2], t[3])
         outs = s.sample((0, 1, 2))
         assert list_stats(s._plan)[key] > 0, name
@@ -130,7 +134,7 @@ def test_fused_first_at_bench_size_equals_two_launches(Sampler):
     outs = {}
     for fused in (True, False):
         with env("PIGS_NO_FUSED_FIRST", None if fused else "1"), torch.no_grad():
-            s = Sampler(False, backend="binned", fuse="all")
+            s = Sampler(False, backend="binned", fuse="all", defer_lists=True)
             s.preprocess(t["means"], t["values"], None, t["conics"], pts)
             outs[fused] = [o.clone() for o in s.sample((0, 1, 2))]
             again = s.sample_gaussians()                     # cached

@@ -9,9 +9,13 @@ import numpy as np
 import pytest
 import torch
 
-from test_binned_gpu import check_case, random_gaussians, rel, dev32
+from test_binned_gpu import check_case, random_gaussians, dev32, rel as _rel
 
 pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return _rel(a, b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else b)
 
 
 @pytest.fixture(scope="module")
@@ -101,7 +105,7 @@ def test_jittered_lattice_and_nonfinite_points(Sampler, hip_lib):
     means, con, values = random_gaussians(rng, 500, 1, log_sigma_mean=-2.6, log_sigma_std=0.4)
     g = grid(64, 48, lo=(-1, -1), hi=(1, 1))
     step = np.array([2 / 63, 2 / 47])
-    jit = g + rng.uniform(-0.3, 0.3, g.shape) * step        # rows stay monotone in x: still a lattice in row order
+    jit = g + rng.uniform(-0.2, 0.2, g.shape) * step        # rows stay monotone in x: still a lattice in row order
     s = check_case(Sampler, means, con, values, jit, orders=(0, 1, 2), gtol="bound")
     assert lattice_of(s, hip_lib) == (64, 48)
     # a NaN point: the index tiles are "not compact", the sort takes over; the NaN point's outputs are NaN,

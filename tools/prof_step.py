@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--lat", type=int, default=256)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--defer", action="store_true", help="PIGS_BUILD_DEFER_LISTS: the first forward builds the tile lists in its own launch")
     a = ap.parse_args()
     import importlib
     importlib.import_module("pigs_amd.build").ensure_built()      # before anything touches the GPU; never builds behind rocprofv3
@@ -55,7 +56,7 @@ def main():
     gs = synthetic.lattice_gaussians(a.lat, a.lat, a.kappa, seed=0)
     pts = synthetic.grid_samples(a.res, a.res).float().to(dev)
     t = {k: v.float().to(dev) for k, v in gs.items()}
-    s = GaussianSampler(False, fuse="all", backend="binned", reuse_samples=a.mode != "cold")
+    s = GaussianSampler(False, fuse="all", backend="binned", reuse_samples=a.mode != "cold", defer_lists=a.defer)
     req = {k: t[k].clone().requires_grad_(True) for k in ("means", "values", "conics")}
     gouts = None
 
