@@ -440,31 +440,40 @@ def main():
     roofline = roofline_of(sampler, a.kappa)
     binned = sampler._plan is not None
 
-    # ---------------- the launch the cold / warm steps actually end with (round 4) ----------------
-    # preprocess() stops in front of the tile lists (PIGS_BUILD_DEFER_LISTS) and the step's sample() builds them in
-    # the SAME launch as its evaluation (plan_lists_forward_kernel<1,7>): HIP events around that one launch, per step.
-    roofline_first = None
-    if binned:
-        with torch.no_grad():
-            n1 = max(5, min(a.steps, 100))
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
-            gc.disable()
-            for e0, e1 in evs:
-                sampler_w.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
-                e0.record()
-                sampler_w.sample((0, 1, 2))
-                e1.record()
-            torch.cuda.synchronize(dev)
-            gc.enable()
-            f_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-            f_ms = sum(f_ms[: max(1, len(f_ms) * 3 // 4)]) / max(1, len(f_ms) * 3 // 4)      # a host hiccup between the two records is not the kernel
-        fb = 24 * N + 36 * M
-        roofline_first = {"bound": "hbm", "kernel": "plan_lists_forward_kernel<1,7>", "kernel_ms": f_ms, "algorithmic_bytes": fb,
-                          "achieved": fb / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": fb / (f_ms * 1e-3) / HBM_PEAK,
-                          "what": "the first forward of a plan: tile-list build + evaluation of orders 0..2 in ONE launch (what "
-                                  "replaces plan_lists_kernel + tile_forward_kernel<1,7> in the timed steps); algorithmic bytes = the "
-                                  "forward's (the lists are an intermediate); `roofline` above is tile_forward_kernel<1,7> on a built "
-                                  "plan: every further sample_*() call of the same preprocess"}
+    # ---------------- A/B: the tile lists deferred into the first forward's launch (round 4, an option) ----------------
+    # GaussianSampler(defer_lists=True): preprocess() stops in front of the tile lists (PIGS_BUILD_DEFER_LISTS) and the
+    # step's sample() builds them in the SAME launch as its evaluation (plan_lists_forward_kernel<1,7>).  Measured, not
+    # the default: the cold step with it, and HIP events around that one launch.
+    deferred = None
+    if binned and not a.no_extras:
+        try:
+            with torch.no_grad():
+                smp_d = GaussianSampler(False, fuse="all", backend=a.backend, reuse_samples=False, defer_lists=True)
+
+                def step_d():
+                    smp_d.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
+                    return smp_d.sample((0, 1, 2))
+                settle(step_d)
+                n1 = max(5, min(a.steps, 100))
+                dtd = timed_steps(step_d, min(a.warmup, 10), n1)
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
+                gc.disable()
+                for e0, e1 in evs:
+                    smp_d.preprocess(t["means"], t["values"], t["covariances"], t["conics"], pts_d)
+                    e0.record()
+                    smp_d.sample((0, 1, 2))
+                    e1.record()
+                torch.cuda.synchronize(dev)
+                gc.enable()
+                f_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+                f_ms = sum(f_ms[: max(1, len(f_ms) * 3 // 4)]) / max(1, len(f_ms) * 3 // 4)      # a host hiccup between the two records is not the kernel
+            deferred = {"cold_ms_per_step": dtd / n1 * 1e3, "value": M * world / (dtd / n1), "kernel": "plan_lists_forward_kernel<1,7>",
+                        "kernel_ms": f_ms, "steps": n1,
+                        "what": "the cold step with the tile-list build deferred into the first forward's launch (one launch instead of "
+                                "plan_lists_kernel + tile_forward_kernel<1,7>); kernel_ms: HIP events around that launch"}
+            del smp_d
+        except Exception as e:
+            deferred = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     # ---------------- fwd + bwd step (second half of BASELINE.json's metric) ----------------
     fwd_bwd = roofline_bwd = None
@@ -677,7 +686,7 @@ def main():
                    "step": "preprocess (cold: nothing reused) + fused forward (orders 0..2)"},
         "host_issue_ms_per_step": host_cold * 1e3,
         "preheat_ms": preheat_ms, "value_warm_plan": warm["value"], "warm_plan": warm,
-        "roofline": roofline, "roofline_first": roofline_first, "roofline_bwd": roofline_bwd, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
+        "roofline": roofline, "roofline_bwd": roofline_bwd, "deferred_lists": deferred, "fwd_bwd": fwd_bwd, "two_streams": two_streams,
         "kappa_1_3": kappa13, "small": small, "c2": c2, "unordered_points": unordered, "host": sampler.host,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

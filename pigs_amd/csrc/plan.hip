@@ -76,6 +76,7 @@ struct BuildArgs {
     SPoint* spts;
     const float* samples;
     uint32_t M, scells_cap, s_scan_blocks, s_zero_words;
+    uint32_t s_blocks;    // blocks of 1 024 points of the one-pass count (its sample workgroups: one per block, or fewer, striding)
     uint32_t* szero;      // what the bbox launch zeroes for the samples side (s_zero_words): counters + scan aggregates
     // coarse-bin path of the samples build (plan.h): scounts / sagg / sstarts then are the (bin, workgroup) count
     // matrix, its scan aggregates and its scan
@@ -142,7 +143,7 @@ __device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, flo
     x0 = readlane_f(x0, 63); x1 = readlane_f(x1, 63); y0 = readlane_f(y0, 63); y1 = readlane_f(y1, 63);
 }
 
-// Launch 1 of a samples build (PLAN_BBOX_BLOCKS workgroups of 1 024 threads): zero the cell counters (of the
+// Launch 1 of a samples build (PLAN_BBOX_BLOCKS workgroups): zero the cell counters (of the
 // plan too, when one is built alongside); per-workgroup bounding box of the sample points, written as a plain
 // partial.  And what the INDEX-TILED order (plan.h, SampleParams::lat) is decided from, in the same streaming pass:
 // every workgroup finds the first index at which the fast coordinate steps backwards -- the row length rf of a
@@ -154,15 +155,15 @@ __device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, flo
 // COPIED: the sampling kernels read the caller's array through the index arithmetic -- or the points go through
 // the sort.  The pass runs on the row length of the last build of this size (the library's memory, `rf_hint`)
 // while the search is still in flight, and is repeated only when the search finds another one.
-constexpr uint32_t BBOX_THREADS = 1024;
+constexpr uint32_t BBOX_THREADS = 256;      // (1 024-thread workgroups -- 4 096 waves to launch -- cost small point sets ~3 us)
 constexpr uint32_t LAT_SEARCH0 = 2048, LAT_SEARCH1 = 16384;
 __device__ __forceinline__ bool lattice_shape_ok(uint32_t rf, uint32_t n) {
     const uint32_t rs = rf ? n / rf : 0u;
     return rf >= 8u && (rf & 7u) == 0u && rs * rf == n && (rs & 7u) == 0u && n >= 64u;
 }
-__global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
-    __shared__ float sh[16][8];
-    __shared__ uint32_t shk[16];
+__global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
+    __shared__ float sh[4][8];
+    __shared__ uint32_t shk[4];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     zero_words(a.szero, a.s_zero_words);
@@ -189,40 +190,57 @@ __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
         const float d = fabsf(u - v);
         s = d == d ? fmaxf(s, d) : INF;
     };
-    // one streaming pass: the box (first time only) and, with a row length, the neighbour steps
+    // one streaming pass, 8 pairs (float4 = two points) per thread in flight: the box (first time only) and, with a
+    // row length rf, the neighbour steps.  With a row length a thread takes the SAME column pair of 8 consecutive rows:
+    // the point above is then its own previous load (one extra load for the first of its rows), the point to the right
+    // its neighbour lane's (one lane of the wave loads it) -- 9 + 1 loads where point, right and upper neighbour of
+    // every pair were 24 (first launch 8.6 -> 6.x us at 1024^2).
+    constexpr int PB = 8;
     auto pass = [&](uint32_t rf, bool box) {
         ax = ay = bx = by = 0.f;
-        const uint32_t half = rf >> 1;            // rf is even: a float4 never straddles a row end
-        uint32_t i = blockIdx.x * BBOX_THREADS + tid;
-        uint32_t w = rf ? (2u * i + 2u) % rf : 1u;                     // (index of the point behind pair j) mod rf; 0: a row starts there
-        const uint32_t ds = rf ? (2u * stride) % rf : 0u;              // its step from pair j to pair j + stride
-        for (; i < npair; i += 4 * stride) {
-            float4 v[4], up[4];
-            float2 nx[4];
+        if (rf == 0u) {
+            for (uint32_t i = blockIdx.x * BBOX_THREADS + tid; i < npair; i += PB * stride) {
+                float4 v[PB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t j = i + k * stride;
-                const uint32_t jj = j < npair ? j : i;
-                v[k] = pts2[jj];
-                if (rf) {
-                    nx[k] = pts[2u * jj + 2u < n ? 2u * jj + 2u : 2u * jj + 1u];
-                    up[k] = pts2[jj >= half ? jj - half : jj];
+                for (int k = 0; k < PB; ++k) {
+                    const uint32_t j = i + k * stride;
+                    v[k] = pts2[j < npair ? j : i];
+                }
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    if (i + k * stride >= npair) break;
+                    if (box) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
                 }
             }
+        } else {
+            const uint32_t half = rf >> 1;            // pairs per row (rf is even: a float4 never straddles a row end)
+            const uint32_t items = (n / rf / PB) * half;      // (column pair, block of 8 rows): rs is a multiple of 8
+            for (uint32_t g = blockIdx.x * BBOX_THREADS + tid; g - (uint32_t)lane < items; g += stride) {      // whole waves stay in (the shuffles)
+                const bool in = g < items;
+                const uint32_t gg = in ? g : items - 1u;
+                const uint32_t rb = gg / half, c = gg - rb * half;
+                const uint32_t j0 = rb * PB * half + c;
+                float4 v[PB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t j = i + k * stride;
-                if (j >= npair) break;
-                if (box) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
-                if (rf) {
+                for (int k = 0; k < PB; ++k) v[k] = pts2[j0 + (uint32_t)k * half];
+                const float4 up0 = pts2[rb ? j0 - half : j0];
+                const bool last = c == half - 1u;                      // the pair at the end of a row: its right neighbour starts the next row
+                const bool edge = lane == 63 && !last;                 // right neighbour in another wave: loaded
+                float2 nxl[PB];
+#pragma unroll
+                for (int k = 0; k < PB; ++k) nxl[k] = edge ? pts[2u * (j0 + (uint32_t)k * half) + 2u] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < PB; ++k) {
+                    const float rx = __shfl_down(v[k].x, 1), ry = __shfl_down(v[k].y, 1);
+                    if (!in) continue;
+                    if (box) { take(v[k].x, v[k].y); take(v[k].z, v[k].w); }
                     step(ax, v[k].z, v[k].x); step(ay, v[k].w, v[k].y);
-                    if (w != 0u && 2u * j + 2u < n) { step(ax, nx[k].x, v[k].z); step(ay, nx[k].y, v[k].w); }
-                    if (j >= half) {
-                        step(bx, v[k].x, up[k].x); step(by, v[k].y, up[k].y);
-                        step(bx, v[k].z, up[k].z); step(by, v[k].w, up[k].w);
+                    if (!last) { step(ax, edge ? nxl[k].x : rx, v[k].z); step(ay, edge ? nxl[k].y : ry, v[k].w); }
+                    const float4 u = k ? v[k > 0 ? k - 1 : 0] : up0;
+                    if (k || rb) {
+                        step(bx, v[k].x, u.x); step(by, v[k].y, u.y);
+                        step(bx, v[k].z, u.z); step(by, v[k].w, u.w);
                     }
-                    w += ds;
-                    if (w >= rf) w -= rf;
                 }
             }
         }
@@ -231,41 +249,43 @@ __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
     // ---- the candidate row length.  The fast axis is the one along which the first two points differ most, its
     // direction the sign of that step; a row ends where the fast coordinate steps the other way (a jittered lattice
     // keeps its rows as long as the jitter stays below half a step).  key = that first index (NONE: none found).
+    // Thread t looks at the eight steps from point 8 t on; the loads are issued HERE and looked at behind the pass:
+    // one memory round trip for the launch.
     constexpr uint32_t NONE = 0xffffffffu;
-    uint32_t axis = 0u;
-    float dir = 1.f;
-    if (n >= 2u) {
-        const float2 p = pts[0], q = pts[1];
-        axis = fabsf(q.y - p.y) > fabsf(q.x - p.x) ? 1u : 0u;
-        dir = (axis ? q.y - p.y : q.x - p.x) < 0.f ? -1.f : 1.f;
+    const bool search = !a.no_lattice && n >= 64u;
+    float2 e0 = make_float2(0.f, 0.f), e1 = e0, q[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q[k] = e0;
+    if (search) {
+        e0 = pts[0]; e1 = pts[1];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (8u * tid + (uint32_t)k < n) q[k] = pts[8u * tid + (uint32_t)k];
     }
-    auto probe = [&](uint32_t i) -> uint32_t {
-        if (i + 1u >= n) return NONE;
-        const float2 p = pts[i], q = pts[i + 1u];
-        return (axis ? q.y - p.y : q.x - p.x) * dir < 0.f ? i : NONE;
-    };
+    // the pass on the remembered row length (or, without one, for the box alone)
+    const uint32_t hf = search && lattice_shape_ok(a.rf_hint, n) ? a.rf_hint : 0u;
+    pass(hf, true);
+    const uint32_t axis = fabsf(e1.y - e0.y) > fabsf(e1.x - e0.x) ? 1u : 0u;
+    const float dir = (axis ? e1.y - e0.y : e1.x - e0.x) < 0.f ? -1.f : 1.f;
+    auto backward = [&](float2 p, float2 r) { return (axis ? r.y - p.y : r.x - p.x) * dir < 0.f; };
     auto block_min = [&](uint32_t k) -> uint32_t {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) k = min(k, (uint32_t)__shfl_xor((int)k, o));
         __syncthreads();
         if (lane == 0) shk[wave] = k;
         __syncthreads();
-        uint32_t r = shk[0];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) r = min(r, shk[w]);
-        return r;
+        return min(min(shk[0], shk[1]), min(shk[2], shk[3]));
     };
-    const bool search = !a.no_lattice && n >= 64u;
-    uint32_t key = search ? min(probe(tid), probe(tid + 1024u)) : NONE;
-    // the pass on the remembered row length (or, without one, for the box alone), the search's loads in flight beside it
-    const uint32_t hf = search && lattice_shape_ok(a.rf_hint, n) ? a.rf_hint : 0u;
-    pass(hf, true);
+    uint32_t key = NONE;
     if (search) {
+#pragma unroll
+        for (int k = 7; k >= 0; --k)
+            if (8u * tid + (uint32_t)k + 1u < n && backward(q[k], q[k + 1])) key = 8u * tid + (uint32_t)k;
         key = block_min(key);
         if (key == NONE && n > LAT_SEARCH0 + 1u) {
             uint32_t k2 = NONE;
-#pragma unroll 2
-            for (uint32_t i = LAT_SEARCH0 + tid; i < LAT_SEARCH1; i += 1024u) k2 = min(k2, probe(i));
+            for (uint32_t i = LAT_SEARCH0 + tid; i < LAT_SEARCH1 && i + 1u < n; i += BBOX_THREADS)
+                if (backward(pts[i], pts[i + 1u])) k2 = min(k2, i);
             key = block_min(k2);
         }
     }
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(1024) void samples_bbox_kernel(BuildArgs a) {
     if (lane == 0) { sh[wave][0] = x0; sh[wave][1] = y0; sh[wave][2] = x1; sh[wave][3] = y1; sh[wave][4] = ax; sh[wave][5] = ay; sh[wave][6] = bx; sh[wave][7] = by; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 16; ++w) {
+        for (int w = 1; w < 4; ++w) {
             x0 = fminf(x0, sh[w][0]); y0 = fminf(y0, sh[w][1]);
             x1 = fmaxf(x1, sh[w][2]); y1 = fmaxf(y1, sh[w][3]);
             ax = fmaxf(ax, sh[w][4]); ay = fmaxf(ay, sh[w][5]); bx = fmaxf(bx, sh[w][6]); by = fmaxf(by, sh[w][7]);
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     float gm[2] = {0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f};
     float2 pt[4];
     const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
+    uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
     // the first launch's lattice candidate (plan.h): with one, the sample workgroups most likely have nothing to do
     const uint32_t lat_rf = a.do_samples ? a.sparams->lat_cand[0] : 0u;
     const uint32_t lat_axis = a.do_samples ? a.sparams->lat_cand[1] : 0u;
@@ -447,8 +467,14 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         // index-tiled: nothing to key, count or move (block-uniform)
     } else if (a.coarse) {
         samples_hist_part(a, blockIdx.x - gblocks, sg, lh, lane);
-    } else {
-        if (lat_rf != 0u) load_points();      // a candidate that was not compact after all: the loads were not issued early
+    } else
+    // the one-pass count: a sample workgroup takes 1 024 points at a time -- one block where the launch has a workgroup
+    // per block; where the host expected a lattice (rf_hint) and launched an eighth of them, the workgroups stride
+    // over the blocks: the points that were no lattice after all are still all counted, by fewer hands
+    for (uint32_t sb = blockIdx.x - gblocks; sb < a.s_blocks; sb += gridDim.x - gblocks) {
+        const bool first = sb == blockIdx.x - gblocks;
+        i0 = (sb * 4 + (threadIdx.x >> 6)) * 256 + lane;
+        if (!first || lat_rf != 0u) load_points();      // (the first block's loads were issued early unless a lattice candidate stood)
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
         uint32_t id[4], base[4];
         Run r[4];
@@ -476,7 +502,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             const uint32_t b = __shfl(base[k], r[k].start);
             if (i < a.M) a.skey[i] = make_uint2(id[k], b + (uint32_t)(lane - r[k].start));
         }
-        if (((blockIdx.x - gblocks) & 31u) == 0u && threadIdx.x < 64u) {      // a sample of the waves (one in 128): runs per point (SampleParams::order_stat)
+        if ((sb & 31u) == 0u && threadIdx.x < 64u) {      // a sample of the waves (one in 128): runs per point (SampleParams::order_stat)
             uint32_t runs = 0, pts = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -825,6 +851,8 @@ __global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
             if (rk[k] != 0xffffffffu) atomicAdd(&cnt[rk[k]], 1u);
         }
     } else {
+        // (a segment longer than one batch: a dense patch of a clustered cloud, 100 k points and more in one bin -- 73 us
+        // for this launch at sigma = 0.15; batches of 4 loads with the next batch in flight were measured SLOWER: 118 us)
         for (uint32_t p = seg0 + tid; p < seg1; p += 1024u) atomicAdd(&cnt[key_of(tmp4[p])], 1u);
     }
     __syncthreads();
@@ -999,17 +1027,19 @@ __global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
 #define PIGS_XCD_CHUNK 256
 #endif
 template <uint32_t CHUNK>
-__device__ __forceinline__ uint32_t xcd_block_chunk(uint32_t nblocks) {      // nblocks: the blocks that take part (helpers behind them keep out)
-    if constexpr (CHUNK > 0) {
+__device__ __forceinline__ uint32_t xcd_block_chunk(uint32_t nblocks, uint32_t b) {      // nblocks: the blocks that take part; b: this one's index among them
+    if constexpr (CHUNK > 0) {                                                            //   (helper workgroups in front of them: a multiple of 8, keep out)
         constexpr uint32_t GROUP = 8u * CHUNK;
-        const uint32_t b = blockIdx.x, g = b / GROUP, r = b % GROUP;
+        const uint32_t g = b / GROUP, r = b % GROUP;
         if ((g + 1) * GROUP > nblocks) return b;
         return g * GROUP + (r & 7u) * CHUNK + (r >> 3);
     } else {
-        return blockIdx.x;
+        return b;
     }
 }
-__device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) { return xcd_block_chunk<PIGS_XCD_CHUNK>(nblocks); }
+template <uint32_t CHUNK>
+__device__ __forceinline__ uint32_t xcd_block_chunk(uint32_t nblocks) { return xcd_block_chunk<CHUNK>(nblocks, blockIdx.x); }
+__device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks, uint32_t b) { return xcd_block_chunk<PIGS_XCD_CHUNK>(nblocks, b); }
 
 // ------------------------------------------------------------------------------------------
 // Launch 5 of a plan build: the tile lists.  One wave = LISTS_TPW consecutive tiles (4 tiles = 256
@@ -1025,11 +1055,12 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t nblocks) { return xcd_blo
 #endif
 constexpr int LISTS_TPW = PIGS_LISTS_TPW;
 constexpr int SURV_CAP = 128;
+template <int TPW>
 struct ListsLds {
     TravLds trav;
     float4 sa[SURV_CAP];              // survivor: {mux, muy, a, b}
     float4 sb[SURV_CAP];              //           {c, -b/c, -b/a, sorted index (bits)}
-    float4 gbox[LISTS_TPW * 4];       // boxes of the groups: {x0, y0, x1, y1}
+    float4 gbox[TPW * 4];       // boxes of the groups: {x0, y0, x1, y1}
     uint32_t sel[SURV_CAP];           // positions of the survivors that reach the tile in hand
     uint32_t bmask[SURV_CAP];         // per survivor: the four tiles' masks, byte t = wide << 4 | narrow
 };
@@ -1044,19 +1075,23 @@ struct ListArgs {
     float q_f;            // the narrow cut-off (pv.q_max is the wide one)
 };
 
-// the lists of the LISTS_TPW tiles from tile0 (one wave)
-__device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& lds, uint32_t tile0, int lane) {
+// the lists of the TPW tiles from tile0 (one wave).  TPW = 4 (a 4 x 4 block of sample cells: the traversal of the grid is
+// shared by four tiles) where the launch fills the chip; TPW = 1 for small point sets (LISTS_SMALL_TILES): the launch's
+// time is the serial life of ONE wave there (21 us at 65 536 points with four tiles per wave, the chip nearly idle), and
+// a wave with a quarter of the work has a shorter life.
+template <int TPW>
+__device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TPW>& lds, uint32_t tile0, int lane) {
     const PlanView& pv = a.pv;
     const uint32_t ntiles = a.sv.ntiles;
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
     const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
     const float INF = __builtin_huge_valf();
-    SPoint sp[LISTS_TPW];
-    bool valid[LISTS_TPW];
+    SPoint sp[TPW];
+    bool valid[TPW];
     const PointOrder po = point_order(a.sv);
 #pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         const uint32_t m = (tile0 + (uint32_t)t) * TILE_POINTS + (uint32_t)lane;
         valid[t] = m < a.sv.M;           // also false for every point of a tile behind the last one
         sp[t] = SPoint{0.f, 0.f, 0u};
@@ -1064,7 +1099,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
     }
     float bx0 = INF, bx1 = -INF, by0 = INF, by1 = -INF;
 #pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         float x0 = valid[t] ? sp[t].x : INF, x1 = valid[t] ? sp[t].x : -INF;
         float y0 = valid[t] ? sp[t].y : INF, y1 = valid[t] ? sp[t].y : -INF;
         row_box_dpp(x0, x1, y0, y1);
@@ -1090,7 +1125,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
     // spans dozens of cells: its list would run to hundreds) goes to the per-point walk without being listed at
     // all: the traversal of such a box is the list build's own tail (thousands of candidates in one wave).
     if ((bx1 - bx0) * gg.inv_s0 * ((by1 - by0) * gg.inv_s0) > POINTS_MODE_BLOCK_CELLS && walk_candidates() <= 4.f * (float)cap) {
-        for (int t = 0; t < LISTS_TPW; ++t) {
+        for (int t = 0; t < TPW; ++t) {
             if (tile0 + (uint32_t)t >= ntiles) break;
             if (lane < TILE_HDR_WORDS)
                 a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (TILE_MODE_POINTS << TILE_MODE_SHIFT) : 0u;
@@ -1098,10 +1133,10 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
         }
         return;
     }
-    uint32_t n[LISTS_TPW], ng[LISTS_TPW][4];
-    bool overflow[LISTS_TPW], goverflow[LISTS_TPW];       // the tile list / one of the group lists is full
+    uint32_t n[TPW], ng[TPW][4];
+    bool overflow[TPW], goverflow[TPW];       // the tile list / one of the group lists is full
 #pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         n[t] = 0; overflow[t] = false; goverflow[t] = false;
 #pragma unroll
         for (int g = 0; g < 4; ++g) ng[t][g] = 0;
@@ -1111,7 +1146,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
     // The block list lives in the tile-list slabs of the block's tiles (8-byte entries {sorted index, masks}):
     // capacity = tiles x cap / 2.
     uint2* const blist = (uint2*)(a.tlist + (size_t)tile0 * cap);
-    const uint32_t tiles_here = ntiles - tile0 < (uint32_t)LISTS_TPW ? ntiles - tile0 : (uint32_t)LISTS_TPW;
+    const uint32_t tiles_here = ntiles - tile0 < (uint32_t)TPW ? ntiles - tile0 : (uint32_t)TPW;
     const uint32_t cap_b = tiles_here * cap / 2;
     uint32_t nb = 0;
     bool boverflow = false;
@@ -1127,7 +1162,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
         wave_lds_fence();
 #endif
 #pragma unroll
-        for (int t = 0; t < LISTS_TPW; ++t) {
+        for (int t = 0; t < TPW; ++t) {
             if (tile0 + (uint32_t)t >= ntiles) continue;
             float4 gb[4];
 #pragma unroll
@@ -1238,20 +1273,20 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
     // (TILE_MODE_GROUPS) -- which must then hold the WIDE set: they are rebuilt below.
     const bool two_cuts = pv.q_max > a.q_f;
     bool any_rare = false;
-    bool rebuild[LISTS_TPW];
+    bool rebuild[TPW];
 #if PIGS_BWD_BLOCK
     // The block list serves the backward of all four tiles when it fits and every group list (the forward's) does;
     // otherwise (very wide Gaussians, scattered points) the tiles fall back one by one: group lists only
     // (rebuilt with the wide cut-off: the backward then walks those) or record ranges.
     bool block_ok = !boverflow;
 #pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) block_ok = block_ok && !(tile0 + (uint32_t)t < ntiles && goverflow[t]);
+    for (int t = 0; t < TPW; ++t) block_ok = block_ok && !(tile0 + (uint32_t)t < ntiles && goverflow[t]);
     if (lane == 0) a.hdr[(size_t)tile0 * TILE_HDR_WORDS + 5] = block_ok ? (nb | 0x80000000u) : 0u;
 #pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) overflow[t] = !block_ok;      // as if every tile list had overflowed
+    for (int t = 0; t < TPW; ++t) overflow[t] = !block_ok;      // as if every tile list had overflowed
 #endif
 #pragma unroll
-    for (int t = 0; t < LISTS_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         rebuild[t] = false;
         if (tile0 + (uint32_t)t >= ntiles) { overflow[t] = false; continue; }
         const bool tl_over = overflow[t];
@@ -1297,15 +1332,15 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
     // not fit: the tile keeps the grid's record ranges around its box instead (pairs {first, length}; the
     // sampling kernels test the ranges' records against the group boxes themselves); when even those do
     // not fit, the single range of all Gaussians.
-    for (int t = 0; t < LISTS_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         const bool mine_rebuild = __builtin_amdgcn_readfirstlane((int)(t == 0   ? rebuild[0]
-                                                                       : t == 1 ? rebuild[LISTS_TPW > 1 ? 1 : 0]
-                                                                       : t == 2 ? rebuild[LISTS_TPW > 2 ? 2 : 0]
-                                                                                : rebuild[LISTS_TPW > 3 ? 3 : 0])) != 0;
+                                                                       : t == 1 ? rebuild[TPW > 1 ? 1 : 0]
+                                                                       : t == 2 ? rebuild[TPW > 2 ? 2 : 0]
+                                                                                : rebuild[TPW > 3 ? 3 : 0])) != 0;
         bool mine = __builtin_amdgcn_readfirstlane((int)(t == 0   ? overflow[0]
-                                                         : t == 1 ? overflow[LISTS_TPW > 1 ? 1 : 0]
-                                                         : t == 2 ? overflow[LISTS_TPW > 2 ? 2 : 0]
-                                                                  : overflow[LISTS_TPW > 3 ? 3 : 0])) != 0;
+                                                         : t == 1 ? overflow[TPW > 1 ? 1 : 0]
+                                                         : t == 2 ? overflow[TPW > 2 ? 2 : 0]
+                                                                  : overflow[TPW > 3 ? 3 : 0])) != 0;
         if (!mine && !mine_rebuild) continue;
         float4 gb[4];
 #pragma unroll
@@ -1385,17 +1420,19 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds& l
 }
 
 // the same strips of the domain on the same XCD as in the sampling kernels, which then find a tile's
-// lists in the L2 that wrote them (a workgroup here is 4 * LISTS_TPW tiles; forward 27.05 -> 26.4 us)
+// lists in the L2 that wrote them (a workgroup here is 4 * TPW tiles; forward 27.05 -> 26.4 us)
+template <int TPW>
 __device__ __forceinline__ uint32_t lists_tile0(int wave) {
-    return (xcd_block_chunk<PIGS_XCD_CHUNK / LISTS_TPW>(gridDim.x) * 4 + (uint32_t)wave) * LISTS_TPW;
+    return (xcd_block_chunk<PIGS_XCD_CHUNK / TPW>(gridDim.x) * 4 + (uint32_t)wave) * TPW;
 }
+template <int TPW>
 __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
-    __shared__ ListsLds lds_all[4];
+    __shared__ ListsLds<TPW> lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile0 = lists_tile0(wave);
+    const uint32_t tile0 = lists_tile0<TPW>(wave);
     if (tile0 >= a.sv.ntiles) return;
-    build_block_lists(a, lds_all[wave], tile0, lane);
+    build_block_lists<TPW>(a, lds_all[wave], tile0, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1783,17 +1820,23 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nmain = (sv.ntiles + FW - 1u) / FW;
-    if (blockIdx.x >= nmain) {
+    // The helper workgroups come FIRST in the launch (round 4): their walks are chains of dependent loads that take
+    // many times a tile's life, and dispatched behind the main ones (round 3) they were the launch's tail -- a
+    // clamped-normal cloud's forward took 56 us for 30 us of tile work.  They leave at once when the plan queued no
+    // TILE_MODE_POINTS tile.  Their number is a multiple of 8: workgroup i of the main ones still runs on XCD i % 8.
+    constexpr uint32_t NHELP = POINT_HELPER_BLOCKS * 4u / FW;
+    static_assert(NHELP % 8u == 0u, "the main workgroups keep their XCD");
+    if (blockIdx.x < NHELP) {
         // helper workgroups (plan.h, TILE_MODE_POINTS): four points at a time, 16 lanes per point, lane = candidate
         const uint32_t n = pv.params->n_points;
         if (n == 0u) return;
         const float q_f = pv.params->q_f;
-        const uint32_t hw = (blockIdx.x - nmain) * FW + (uint32_t)wave, nhw = (gridDim.x - nmain) * FW;
+        const uint32_t hw = blockIdx.x * FW + (uint32_t)wave, nhw = NHELP * FW;
         for (uint32_t qd = hw; qd < n * 16u; qd += nhw)
             forward_points_quad<C, MASK>(pv, sv, pv.ptiles[qd >> 4], qd & 15u, lane, q_f, o0, o1, o2, o3, rz);
         return;
     }
-    const uint32_t tile = xcd_block_chunk<PIGS_XCD_CHUNK * 4 / FW>(nmain) * FW + (uint32_t)wave;
+    const uint32_t tile = xcd_block_chunk<PIGS_XCD_CHUNK * 4 / FW>(nmain, blockIdx.x - NHELP) * FW + (uint32_t)wave;
     if (tile >= sv.ntiles) return;
     forward_tile<C, MASK>(pv, sv, tile, lane, lds_all[wave], o0, o1, o2, o3, rz);
 }
@@ -1812,14 +1855,14 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
 template <int C, int MASK>
 __global__ __launch_bounds__(256) void plan_lists_forward_kernel(ListArgs a, float* __restrict__ o0, float* __restrict__ o1,
                                                                  float* __restrict__ o2, float* __restrict__ o3, Resid<float> rz) {
-    __shared__ ListsLds lds_all[4];
-    static_assert(sizeof(FwdLds) <= sizeof(ListsLds), "the forward's queues live in the list build's LDS");
+    __shared__ ListsLds<LISTS_TPW> lds_all[4];
+    static_assert(sizeof(FwdLds) <= sizeof(ListsLds<LISTS_TPW>), "the forward's queues live in the list build's LDS");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile0 = lists_tile0(wave);
+    const uint32_t tile0 = lists_tile0<LISTS_TPW>(wave);
     const uint32_t ntiles = a.sv.ntiles;
     if (tile0 >= ntiles) return;
-    build_block_lists(a, lds_all[wave], tile0, lane);
+    build_block_lists<LISTS_TPW>(a, lds_all[wave], tile0, lane);
     // what this wave's lanes stored (headers, group lists) is read back by other lanes of it: the stores have
     // reached the L2 before the first load is issued
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2194,12 +2237,12 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void tile_backward_ker
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nmain = (sv.ntiles + 3u) / 4u;
-    if (blockIdx.x >= nmain) {
-        backward_points_helper<C, MASK>(pv, sv, (blockIdx.x - nmain) * 4u + (uint32_t)wave, (gridDim.x - nmain) * 4u, lane, G0p, G1p,
-                                        G2p, G3p, rz);
+    static_assert(POINT_HELPER_BLOCKS % 8u == 0u, "the main workgroups keep their XCD");
+    if (blockIdx.x < POINT_HELPER_BLOCKS) {        // the helpers come first in the launch (tile_forward_kernel)
+        backward_points_helper<C, MASK>(pv, sv, blockIdx.x * 4u + (uint32_t)wave, POINT_HELPER_BLOCKS * 4u, lane, G0p, G1p, G2p, G3p, rz);
         return;
     }
-    const uint32_t tile = spread_tile(xcd_block(nmain) * 4 + (uint32_t)wave, sv.ntiles);
+    const uint32_t tile = spread_tile(xcd_block(nmain, blockIdx.x - POINT_HELPER_BLOCKS) * 4 + (uint32_t)wave, sv.ntiles);
     if (tile >= sv.ntiles) return;
     backward_tile<C, MASK>(pv, sv, tile, lds_all[wave], lane, G0p, G1p, G2p, G3p, rz);
 }
@@ -2452,14 +2495,17 @@ size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
     return make_plan_layout(N, M, c).total_bytes;
 }
 
+constexpr int64_t LATTICE_MIN_POINTS = 1 << 18;
 static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, const void* samples, bool coarse) {
     char* b = (char*)sws;
     a.sparams = (SampleParams*)(b + s.off_params);
     a.sboxes = (float4*)(b + s.off_boxes);
     a.slat = (float4*)(b + s.off_lat);
-    {
+    {   // index-tiled order: from LATTICE_MIN_POINTS points on (below, what the sort of a lattice costs -- ~1 us of the count
+        // and scatter launches per 131 072 points -- is less than the ~2.5 us its detection adds to the first launch:
+        // 256^2 grid, cold step 52.3 us index-tiled against 49.5 sorted); PIGS_LATTICE=1 / 0: always / never
         const char* e = getenv("PIGS_LATTICE");
-        a.no_lattice = e && e[0] == '0';
+        a.no_lattice = e ? e[0] == '0' : s.M < LATTICE_MIN_POINTS;
     }
     a.skey = (uint2*)(b + s.off_skey);
     a.spts = (SPoint*)(b + s.off_spts);
@@ -2768,7 +2814,15 @@ static ListArgs make_list_args(const PlanLayout& p, const SamplesLayout& s, void
     la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
     return la;
 }
-static dim3 lists_grid(const SamplesLayout& s) { return dim3((s.ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)); }
+// Small point sets (a list launch of fewer tiles than this is one sparse generation of waves): one tile per wave.
+// PIGS_BWD_BLOCK builds keep four (the block lists are per four tiles).
+constexpr uint32_t LISTS_SMALL_TILES = 4096;
+static void launch_lists(uint32_t ntiles, const ListArgs& la, hipStream_t stream) {
+    if (ntiles <= LISTS_SMALL_TILES && !PIGS_BWD_BLOCK && LISTS_TPW != 1)
+        hipLaunchKernelGGL(plan_lists_kernel<1>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, la);
+    else
+        hipLaunchKernelGGL(plan_lists_kernel<LISTS_TPW>, dim3((ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)), dim3(256), 0, stream, la);
+}
 
 // The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
 // (build_plan) or both in the same four launches, then the tile lists.
@@ -2801,7 +2855,10 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {
         hipLaunchKernelGGL(plan_gauss_build_kernel, dim3(fused_blocks), dim3(256), 0, stream, a);
     } else {
-        const uint32_t count_wgs = coarse ? s.h_wgs : (uint32_t)((M + 1023) / 1024);
+        // a lattice expected (the row length of the last build of this size): an eighth of the one-pass count's workgroups
+        // -- they leave at once when the points are index-tiled, and stride over the blocks when they are not
+        a.s_blocks = (uint32_t)((M + 1023) / 1024);
+        const uint32_t count_wgs = coarse ? s.h_wgs : (a.rf_hint && !a.no_lattice ? (a.s_blocks + 7u) / 8u : a.s_blocks);
         hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? count_wgs : 0u)), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? a.s_scan_blocks : 0u)),
                            dim3(256), 0, stream, a);
@@ -2819,7 +2876,7 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
         }
     }
     if (do_plan && build_lists && !defer_lists)
-        hipLaunchKernelGGL(plan_lists_kernel, lists_grid(s), dim3(256), 0, stream, make_list_args(p, s, ws, sws, q_max, a.q_max));
+        launch_lists(s.ntiles, make_list_args(p, s, ws, sws, q_max, a.q_max), stream);
     const int rc = launch_status();
     if (do_plan) defer_set(ws, build_lists && defer_lists && rc == PIGS_OK, q_max, a.q_max);
     if (do_plan && build_lists && !defer_lists && rc == PIGS_OK) plan_note_points(p, ws, stream);
@@ -2896,7 +2953,7 @@ static int plan_forward_c(const PlanView& pv_in, const SamplesView& sv, int mask
             }
         }
 #undef PIGS_FUSED
-        if (!done) hipLaunchKernelGGL(plan_lists_kernel, lgrid, dim3(256), 0, stream, la);
+        if (!done) launch_lists(sv.ntiles, la, stream);
     }
 #define PIGS_CASE(MK)                                                                                          \
     case MK:                                                                                                   \
@@ -2993,7 +3050,7 @@ int plan_backward(void* ws, size_t ws_bytes, const void* sws, size_t sws_bytes, 
         DeferredLists d{};
         if (defer_take(ws, d)) {
             clear_hip_error();
-            hipLaunchKernelGGL(plan_lists_kernel, lists_grid(s), dim3(256), 0, stream, make_list_args(p, s, ws, sws, d.q_f, d.q_wide));
+            launch_lists(s.ntiles, make_list_args(p, s, ws, sws, d.q_f, d.q_wide), stream);
             const int rc = launch_status();
             if (rc != PIGS_OK) return rc;
             plan_note_points(p, ws, stream);

@@ -71,3 +71,68 @@ def test_float32_error_of_ill_conditioned_conics_is_the_quadratic_forms_cancella
     assert err.max() <= 5e-3 * top
     print(f"{backend}: ill-conditioned float32 max error {err.max() / top:.2e} of the largest value "
           f"(bound {bound.max() / top:.2e}); well-conditioned {res['well'][torch.float32][0].max() / res['well'][torch.float32][1]:.2e}")
+
+
+# The 50 of the first 1 500 cases of tools/fuzz_dense.py (rng seed 5000 + k, the adversarial generator of
+# tests/test_fuzz_gpu.py cut to 300 Gaussians x 500 points) whose float32 dense results leave the 1e-5 bar; measured
+# on MI355X, round 4 (gpurun_out/r4_fuzz_dense.txt): worst 1.1e-3 / 1.8e-3 / 5.8e-4 / 2.2e-3 in the outputs of orders
+# 0..3, 5.9e-4 in the gradients; float64 on the same cases: 5e-13 / 2e-12.
+OVER_THE_BAR = [2, 48, 78, 130, 143, 158, 216, 223, 224, 241, 264, 296, 366, 372, 395, 423, 430, 449, 487, 489, 523, 534, 627, 630,
+                664, 711, 736, 751, 759, 768, 780, 793, 832, 848, 852, 925, 1005, 1085, 1106, 1118, 1184, 1216, 1218, 1220, 1234,
+                1287, 1358, 1373, 1384, 1484]
+
+
+def fuzz_errors(seed, dtype):
+    """The measure of tools/fuzz_dense.py: outputs of orders 0..3 against max(largest value, the term's own scale
+    |v| lambda^(k/2)), gradients against their largest entry times the same understatement factor."""
+    from diff_gaussian_sampling import GaussianSampler
+    from test_fuzz_gpu import make_case
+    rng = np.random.default_rng(5000 + seed)
+    means, values, con, pts = make_case(rng)
+    means, values, con, pts = means[:300], values[:300], con[:300], pts[:500]
+    lam = (con[:, 0] + con[:, 2]) / 2 + np.sqrt(((con[:, 0] - con[:, 2]) / 2) ** 2 + con[:, 1] ** 2)
+    term = [float((np.abs(values).max(1) * lam ** (k / 2)).max()) for k in range(4)]
+    t = [torch.tensor(a, dtype=dtype, device="cuda") for a in (means, values, con, pts)]
+    args = [x.cpu().double().numpy() for x in (t[0], t[2], t[1], t[3])]     # the rounded inputs
+    for x in t[:3]:
+        x.requires_grad_(True)
+    s = GaussianSampler(False, backend="dense", fuse="all")
+    s.preprocess(t[0], t[1], None, t[2], t[3])
+    o = s.sample((0, 1, 2, 3))
+    exp = c_oracle.forward(*args, orders=(0, 1, 2, 3))
+    g = np.random.default_rng(seed)
+    rs = [g.uniform(-1, 1, exp[k].shape) for k in range(4)]
+    sum((x * torch.tensor(r, dtype=dtype, device="cuda")).sum() for x, r in zip(o, rs)).backward()
+    em, ec, ev = c_oracle.backward(*args, {k: torch.tensor(r, dtype=dtype).double().numpy() for k, r in enumerate(rs)})
+    errs, under = [], 1.0
+    for k in range(4):
+        a = o[k].detach().cpu().double().numpy()
+        top = np.abs(exp[k]).max()
+        errs.append(np.abs(a - exp[k]).max() / max(top, term[k], 1e-300))
+        under = max(under, term[k] / max(top, 1e-300))
+    for a, e in ((t[0].grad, em), (t[1].grad, ev), (t[2].grad, ec)):
+        a = a.cpu().double().numpy()
+        errs.append(np.abs(a - e).max() / max(np.abs(e).max() * under, 1e-300) if np.isfinite(a).all() else np.inf)
+    rho2 = con[:, 1] ** 2 / (con[:, 0] * con[:, 2])          # squared correlation of every Gaussian
+    return np.array(errs), float(rho2.max())
+
+
+def test_the_fifty_adversarial_cases_outside_1e5_stay_at_their_measured_level(hip_lib):
+    """float32 dense against the fp64 oracle on the cases tools/fuzz_dense.py found outside the bar: float64 is exact
+    on every one of them (the kernels' arithmetic is right), float32 stays inside the measured level (5e-3 asserted;
+    2.2e-3 measured), every such case holds a Gaussian with rho^2 > 0.999 (the three terms of its quadratic form are
+    more than 1 000 times their sum: necessary, not sufficient), and the other cases of the first 60 are inside the bar."""
+    worst32 = np.zeros(7)
+    for seed in OVER_THE_BAR:
+        e64, _ = fuzz_errors(seed, torch.float64)
+        assert (e64[:4] <= 1e-11).all() and (e64[4:] <= 5e-11).all(), (seed, e64)
+        e32, rho2 = fuzz_errors(seed, torch.float32)
+        assert np.isfinite(e32).all() and (e32 <= 5e-3).all(), (seed, e32)
+        assert rho2 > 0.999, (seed, rho2)
+        worst32 = np.maximum(worst32, e32)
+    assert worst32.max() > 1e-5          # the limit is real: if this fails the kernels have become better than documented
+    inside = [k for k in range(60) if k not in OVER_THE_BAR]
+    for seed in inside:
+        e32, _ = fuzz_errors(seed, torch.float32)
+        assert (e32[:4] <= 1e-5).all() and (e32[4:] <= 5e-5).all(), (seed, e32)
+    print("float32 worst over the 50 cases: out0..3 " + " ".join("%.1e" % x for x in worst32[:4]) + " | grads " + " ".join("%.1e" % x for x in worst32[4:]))

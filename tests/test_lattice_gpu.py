@@ -76,8 +76,9 @@ CASES = [
 def test_lattices_are_index_tiled_and_match_the_oracle(Sampler, hip_lib, name, pts, want):
     rng = np.random.default_rng(7)
     means, con, values = random_gaussians(rng, 600, 1, log_sigma_mean=-2.6, log_sigma_std=0.5)
-    s = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
-    assert lattice_of(s, hip_lib) == want
+    with lattice_env("1"):           # (without the variable the index-tiled order starts at 2^18 points)
+        s = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
+        assert lattice_of(s, hip_lib) == want
     with lattice_env("0"):
         s = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
         assert lattice_of(s, hip_lib) == (0, 0)
@@ -92,15 +93,17 @@ def test_a_lattice_candidate_that_is_not_compact_is_sorted(Sampler, hip_lib):
     rows = rng.permutation(64)
     rows = np.concatenate(([0], rows[rows != 0]))        # row 0 stays first: the candidate is found
     scrambled = g[rows].reshape(-1, 2)
-    s = check_case(Sampler, means, con, values, scrambled, orders=(0, 1, 2), gtol="bound")
-    assert lattice_of(s, hip_lib) == (0, 0)
-    # columns in no order inside every row: the first descent comes early, no candidate at all
-    cols = g[:, rng.permutation(64)].reshape(-1, 2)
-    s = check_case(Sampler, means, con, values, cols, orders=(0, 1, 2), gtol="bound")
-    assert lattice_of(s, hip_lib) == (0, 0)
+    with lattice_env("1"):
+        s = check_case(Sampler, means, con, values, scrambled, orders=(0, 1, 2), gtol="bound")
+        assert lattice_of(s, hip_lib) == (0, 0)
+        # columns in no order inside every row: the first descent comes early, no candidate at all
+        cols = g[:, rng.permutation(64)].reshape(-1, 2)
+        s = check_case(Sampler, means, con, values, cols, orders=(0, 1, 2), gtol="bound")
+        assert lattice_of(s, hip_lib) == (0, 0)
 
 
-def test_jittered_lattice_and_nonfinite_points(Sampler, hip_lib):
+def test_jittered_lattice_and_nonfinite_points(Sampler, hip_lib, monkeypatch):
+    monkeypatch.setenv("PIGS_LATTICE", "1")
     rng = np.random.default_rng(13)
     means, con, values = random_gaussians(rng, 500, 1, log_sigma_mean=-2.6, log_sigma_std=0.4)
     g = grid(64, 48, lo=(-1, -1), hi=(1, 1))
@@ -124,10 +127,11 @@ def test_jittered_lattice_and_nonfinite_points(Sampler, hip_lib):
     assert rel(u[keep], ud[keep]) < 1e-5
 
 
-def test_index_tiled_samples_are_reused_and_survive_new_gaussians(Sampler, hip_lib):
+def test_index_tiled_samples_are_reused_and_survive_new_gaussians(Sampler, hip_lib, monkeypatch):
     """The reference's roll-out (main_pn.py:317-324): new Gaussians on the same grid every step -- the index-tiled
     samples half is built once and shared."""
     from oracle import c_oracle
+    monkeypatch.setenv("PIGS_LATTICE", "1")
     rng = np.random.default_rng(17)
     pts = dev32(grid(96, 64))
     s = Sampler(False, backend="binned", fuse="all")
@@ -146,8 +150,9 @@ def test_index_tiled_samples_are_reused_and_survive_new_gaussians(Sampler, hip_l
 
 
 def test_bench_grid_is_index_tiled_and_equals_the_sorted_build(Sampler, hip_lib):
-    """C3's own points (1024^2 grid, 65 536 lattice Gaussians, kappa 0.5): index-tiled and sorted builds evaluate
-    the same pairs up to the order inside a tile; a slice against the oracle."""
+    """C3's own points (1024^2 grid, 65 536 lattice Gaussians, kappa 0.5; the library's own choice: index-tiled from
+    2^18 points): index-tiled and sorted builds evaluate the same pairs up to the order inside a tile; a slice against
+    the oracle.  And a 256^2 grid is sorted unless asked otherwise."""
     from oracle import c_oracle
     from pigs_amd import synthetic
     gs = synthetic.lattice_gaussians(256, 256, 0.5, seed=0)
@@ -168,3 +173,29 @@ def test_bench_grid_is_index_tiled_and_equals_the_sorted_build(Sampler, hip_lib)
     exp = c_oracle.forward(*args, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
     for o in range(3):
         assert rel(outs[None][o][idx], exp[o]) < 1e-5
+    with lattice_env(None), torch.no_grad():
+        s = Sampler(False, backend="binned")
+        s.preprocess(t["means"], t["values"], None, t["conics"], synthetic.grid_samples(256).float().cuda())
+        s.sample_gaussians()
+        assert lattice_of(s, hip_lib) == (0, 0)
+
+
+def test_points_that_stop_being_a_lattice_after_the_library_expected_one(Sampler, hip_lib, monkeypatch):
+    """The library remembers the row length of the last build of a size and, expecting a lattice, launches an eighth
+    of the one-pass count's workgroups (they leave at once when the points are index-tiled).  When the next point set
+    of that size is no lattice they stride over all the points: same results, and the memory turns around."""
+    monkeypatch.setenv("PIGS_LATTICE", "1")
+    rng = np.random.default_rng(23)
+    means, con, values = random_gaussians(rng, 500, 1, log_sigma_mean=-2.6, log_sigma_std=0.4)
+    g = grid(128, 64)                                     # 8 192 points: 8 blocks of the one-pass count
+    t = [dev32(a) for a in (means, values, con)]
+    s = Sampler(False, backend="binned", reuse_samples=False)
+    for _ in range(4):                                    # the row length lands in the library's memory
+        with torch.no_grad():
+            s.preprocess(t[0], t[1], None, t[2], dev32(g))
+            s.sample_gaussians()
+        torch.cuda.synchronize()
+    assert lattice_of(s, hip_lib) == (128, 64)
+    for pts in (rng.uniform(-1, 1, g.shape), g[rng.permutation(g.shape[0])], g):
+        s2 = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
+        assert lattice_of(s2, hip_lib) == ((128, 64) if pts is g else (0, 0))

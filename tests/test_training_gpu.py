@@ -73,7 +73,7 @@ def run_loop(sampler, device, steps=30, n=16, scale=2.5, dt=0.1):
             uxx = sampler.sample_gaussians_laplacian()
             ux = sampler.sample_gaussians_derivative()
             with torch.no_grad():
-                sampler2 = type(sampler)() if isinstance(sampler, OracleSampler) else sampler.__class__(False)
+                sampler2 = type(sampler)() if isinstance(sampler, OracleSampler) else sampler.__class__(False, backend=sampler.backend)
                 sampler2.preprocess(*prev, samples)
                 u_prev = sampler2.sample_gaussians()
             ut = (u - u_prev) / dt
@@ -110,3 +110,18 @@ def test_training_loss_curve_matches_the_reference_functions(hip_lib):
     gpu = run_loop(GaussianSampler(False), torch.device("cuda"), steps=len(ref))
     rel = np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-12)
     assert rel.max() < 2e-3, (rel.max(), gpu, ref)           # float32 trajectories stay together over 30 steps
+
+
+def test_training_loss_curve_through_the_binned_path(hip_lib):
+    """The optimiser loop on the BINNED path (plans rebuilt every step on new random collocation points, the culled
+    forward and the two-cut-off backward inside an Adam trajectory) against the reference-function loss curve: the
+    truncation at q = 36 / 40 must not move a 30-step float32 trajectory more than the dense path's own 2e-3."""
+    import os
+    from conftest import GOLDEN
+    from diff_gaussian_sampling import GaussianSampler
+    ref = np.load(os.path.join(GOLDEN, "ref_loss_curve_no_mlp.npz"))["losses"]
+    s = GaussianSampler(False, backend="binned")
+    gpu = run_loop(s, torch.device("cuda"), steps=len(ref))
+    assert s._plan is not None
+    rel = np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-12)
+    assert rel.max() < 2e-3, (rel.max(), gpu, ref)

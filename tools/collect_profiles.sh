@@ -4,7 +4,7 @@
 # profiles/ afterwards).  part = stats | pmc | lines | all (default all).  rocprofv3 always with the program
 # itself behind `--`, --pmc passes each in their own run with --kernel-trace only.
 set -e
-tag=${1:-r03}; part=${2:-all}
+tag=${1:-r04}; part=${2:-all}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/${tag}_profiles
 mkdir -p $out
@@ -30,6 +30,25 @@ if [ $part = stats ] || [ $part = all ]; then
     stats fwdbwd $root/tools/prof_step.py fwdbwd --steps 200
     stats cold_k13 $root/tools/prof_step.py cold --steps 100 --kappa 1.3
     stats fwdbwd_k13 $root/tools/prof_step.py fwdbwd --steps 100 --kappa 1.3
+    # round 4 A/B, same box: the index-tiled order off (every grid sorted, as in round 3); the tile lists deferred into
+    # the first forward's launch (plan_lists_forward_kernel); BASELINE configs[1]'s sizes
+    PIGS_LATTICE=0 stats cold_sorted $root/tools/prof_step.py cold --steps 200
+    stats cold_deferred $root/tools/prof_step.py cold --steps 200 --defer
+    stats c2_cold $root/tools/prof_step.py cold --steps 200 --lat 90 --res 256
+    stats c2_fwdbwd $root/tools/prof_step.py fwdbwd --steps 200 --lat 90 --res 256
+    python3 - <<PY > $out/${tag}_step_periods.txt
+import csv, glob
+import numpy as np
+for name, key in (("cold", "samples_bbox"), ("cold_sorted", "samples_bbox"), ("cold_deferred", "samples_bbox"), ("warm", "plan_count"), ("fwdbwd", "plan_count"), ("c2_cold", "samples_bbox")):
+    f = glob.glob("$out/raw_%s/**/*kernel_trace.csv" % name, recursive=True)
+    if not f:
+        continue
+    rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
+    starts = np.array([int(r["Start_Timestamp"]) for r in rows if key in r["Kernel_Name"]])
+    per = np.diff(starts)[20:] / 1e3
+    print(f"{name}: step period on the device timeline (start of {key} to the next): median {np.median(per):.1f} us, mean {per.mean():.1f}, p90 {np.percentile(per, 90):.1f} ({len(per)} steps, under rocprofv3 --kernel-trace)")
+PY
+    cat $out/${tag}_step_periods.txt
 fi
 if [ $part = pmc ] || [ $part = all ]; then
     SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
@@ -50,5 +69,6 @@ if [ $part = lines ] || [ $part = all ]; then
     python3 tools/bench_aggregate.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_aggregate.txt
     for c in grid random shuffled clustered clustered:0.5 clustered:0.3; do python3 tools/preprocess_cases.py $c 0.5 2>&1 | grep kappa; done > $out/${tag}_point_orders.txt
     for c in grid random; do python3 tools/preprocess_cases.py $c 1.3 2>&1 | grep kappa; done >> $out/${tag}_point_orders.txt
+    (cd tools/ubench && ./atomics3; ./atomics4) > $out/${tag}_atomics_ubench.txt 2>&1
     echo "== lines done"
 fi

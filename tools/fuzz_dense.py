@@ -50,3 +50,6 @@ for seed in range(n):
 for dtype, w in worst.items():
     print(dtype, "worst: out0..3", " ".join("%.1e" % x for x in w[:4]), "| grads m,v,c", " ".join("%.1e" % x for x in w[4:]))
 print("over the bar:", len(bad), bad[:8])
+import json
+print("BAD_SEEDS_F32", json.dumps([b[0] for b in bad if "float32" in b[1]]))
+print("BAD_F32_WORST", json.dumps({str(b[0]): b[2] for b in bad if "float32" in b[1]}))
