@@ -1475,6 +1475,47 @@ __device__ __forceinline__ void walk_point(const PlanView& pv, float x, float y,
             for (uint32_t j = j0[r] + (uint32_t)i; j < j1[r]; j += STRIDE) body(j, pv.rec[2 * (size_t)j], pv.rec[2 * (size_t)j + 1]);
     }
 }
+// The same walk with the whole wave in step (four points per wave, 16 lanes per point, STRIDE = 16): `body(have, j, A,
+// B)` is called by all 64 lanes together -- `have` says whether this lane holds a candidate (lanes without one get the
+// all-zero record N) -- as many times per cell row as the longest of the four points' ranges needs, so that the body may
+// exchange data between lanes.  Called with the same (wave-uniform) set of levels by every lane.
+template <typename Body>
+__device__ __forceinline__ void walk_point_instep(const PlanView& pv, float x, float y, int i, Body&& body) {
+    const GaussGrid gg = pv.params->gg;
+    const uint32_t level_mask = pv.params->level_mask;
+    for (int l = 0; l < pv.L; ++l) {
+        if (!(level_mask >> l & 1u)) continue;
+        const int G = pv.G0 >> l;
+        const float inv_s = gg.inv_s0 * __builtin_amdgcn_ldexpf(1.f, -l);
+        const float gmax = (float)(G - 1);
+        const int cx = (int)clampf(floorf((x - gg.ox) * inv_s), 0.f, gmax);
+        const int cy = (int)clampf(floorf((y - gg.oy) * inv_s), 0.f, gmax);
+        const int cx0 = cx > 0 ? cx - 1 : 0, cx1 = cx < G - 1 ? cx + 1 : G - 1;
+        const int cy0 = cy > 0 ? cy - 1 : 0, cy1 = cy < G - 1 ? cy + 1 : G - 1;
+        const int csh = level_shift((uint32_t)(G * G));
+        uint32_t j0[3], j1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = cy0 + r;
+            const uint32_t row = (uint32_t)((yy <= cy1 ? yy : cy1) * G);
+            j0[r] = pv.starts[pv.level_off[l] + ((row + (uint32_t)cx0) << csh)];
+            j1[r] = yy <= cy1 ? pv.starts[pv.level_off[l] + ((row + (uint32_t)cx1 + 1u) << csh)] : j0[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            uint32_t len = j1[r] - j0[r];                  // the same in the 16 lanes of a point
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) len = max(len, (uint32_t)__shfl_xor((int)len, o));
+            len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+            for (uint32_t o = 0; o < len; o += 16u) {
+                const uint32_t j = j0[r] + o + (uint32_t)i;
+                const bool have = j < j1[r];
+                const size_t jj = have ? j : pv.N;
+                body(have, (uint32_t)jj, pv.rec[2 * jj], pv.rec[2 * jj + 1]);
+            }
+        }
+    }
+}
 __device__ __forceinline__ float pair_q(const float4 A, const float4 B, float x, float y) {
     const float dx = x - A.x, dy = y - A.y;
     return A.z * dx * dx + (2.f * A.w * dx + B.x * dy) * dy;
@@ -2214,16 +2255,33 @@ __device__ __forceinline__ void backward_points_helper(const PlanView& pv, const
         Gsym<float, 2, C, EM> G;
         if constexpr (MASK == ORDR) G.load_residual((int64_t)sp.m, G0p, rz);
         else G.load((int64_t)sp.m, G0p, G1p, G2p, G3p);
-        if (!valid) continue;                      // a row without a point (whole rows: the 16 lanes share m)
-        walk_point<16>(pv, sp.x, sp.y, i, [&](uint32_t j, const float4 A, const float4 B) {
-            if (!(pair_q(A, B, sp.x, sp.y) > q_cut)) {
+        // The walk in step over the whole wave (round 4): every lane meets its own (point, Gaussian) pair, and a pair's
+        // NV sums leave as ONE atomic request -- lane = (pair, value), eight pairs per instruction, each a pair's 32-byte
+        // row of gacc -- where an instruction per value with 64 different Gaussians in its lanes was 64 requests, NV
+        // times over (the memory side takes one request per 64-byte segment: a clamped-normal cloud's backward spent
+        // ~150 of its 240 us in these tiles).
+        walk_point_instep(pv, sp.x, sp.y, i, [&](bool have, uint32_t j, const float4 A, const float4 B) {
+            const bool hit = have && valid && !(pair_q(A, B, sp.x, sp.y) > q_cut);
+            float part[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) part[q] = 0.f;
+            if (hit) {
                 const Rec r = make_rec(A, B);
-                float part[NV];
-#pragma unroll
-                for (int q = 0; q < NV; ++q) part[q] = 0.f;
                 bwd_accumulate<float, 2, C, EM, (EM & ORD3) != 0, C == 1>(part, s, r.mu, r.con, r.v, G);
+            }
+            const uint64_t hm = __ballot(hit);
+            const int q = lane & 7, sub = lane >> 3;
+            for (int it = 0; it < 8; ++it) {
+                if (((hm >> (8 * it)) & 0xffull) == 0ull) continue;          // wave-uniform
+                const int src = 8 * it + sub;
+                const uint32_t js = (uint32_t)__shfl((int)j, src);
+                float v = 0.f;
 #pragma unroll
-                for (int q = 0; q < NV; ++q) atomicAdd(&pv.gacc[(size_t)j * 8 + q], part[q]);
+                for (int k = 0; k < NV; ++k) {
+                    const float t = __shfl(part[k], src);
+                    v = q == k ? t : v;
+                }
+                if ((hm >> src & 1ull) && q < NV) atomicAdd(&pv.gacc[(size_t)js * 8 + q], v);
             }
         });
     }
