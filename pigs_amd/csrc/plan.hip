@@ -53,7 +53,7 @@
                               // record (tests pass with either setting).
 #endif
 #ifndef PIGS_BWD_WAVES
-#define PIGS_BWD_WAVES 4      // waves per SIMD the backward kernel's register budget is held to (its LDS allows 4 workgroups per CU)
+#define PIGS_BWD_WAVES 6      // waves per SIMD the backward kernel's register budget is held to (its LDS allows 6 workgroups per CU)
 #endif
 
 namespace pigs {
@@ -851,9 +851,23 @@ __global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
             if (rk[k] != 0xffffffffu) atomicAdd(&cnt[rk[k]], 1u);
         }
     } else {
-        // (a segment longer than one batch: a dense patch of a clustered cloud, 100 k points and more in one bin -- 73 us
-        // for this launch at sigma = 0.15; batches of 4 loads with the next batch in flight were measured SLOWER: 118 us)
-        for (uint32_t p = seg0 + tid; p < seg1; p += 1024u) atomicAdd(&cnt[key_of(tmp4[p])], 1u);
+        // A segment longer than one batch: a dense patch of a clustered cloud, 100 k points and more in one bin -- 73 us for
+        // this launch at sigma = 0.15, a third of that cloud's cold step.  What bounds it is ONE compute unit's memory
+        // stream (the segment is read twice, 16 B per point: 3.7 MB at ~55 GB/s): batches of 4 loads with the next batch
+        // in flight were measured slower (118 us), rounds of 8 loads the same (70), eight workgroups per bin each taking
+        // a slice of the cells but reading the whole segment the same again (74, and 2 048 workgroups to launch cost the
+        // uniform case 60 us).  Sixteen loads per thread and round:
+        for (uint32_t p0 = seg0; p0 < seg1; p0 += 16u * 1024u) {
+            uint4 t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t p = p0 + (uint32_t)k * 1024u + tid;
+                t[k] = p < seg1 ? tmp4[p] : make_uint4(0u, 0u, 0u, 0xffffffffu);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (t[k].w != 0xffffffffu) atomicAdd(&cnt[key_of(t[k])], 1u);
+        }
     }
     __syncthreads();
     // exclusive scan in place: thread t owns the `per` consecutive counters from t * per
@@ -888,9 +902,16 @@ __global__ __launch_bounds__(1024) void samples_binsort_kernel(BuildArgs a) {
         for (int k = 0; k < B; ++k)
             if (rk[k] != 0xffffffffu) place(r[k], rk[k]);
     } else {
-        for (uint32_t p = seg0 + tid; p < seg1; p += 1024u) {
-            const uint4 t = tmp4[p];
-            place(t, key_of(t));
+        for (uint32_t p0 = seg0; p0 < seg1; p0 += 16u * 1024u) {
+            uint4 t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t p = p0 + (uint32_t)k * 1024u + tid;
+                t[k] = p < seg1 ? tmp4[p] : make_uint4(0u, 0u, 0u, 0xffffffffu);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (t[k].w != 0xffffffffu) place(t[k], key_of(t[k]));
         }
     }
 }
@@ -1935,7 +1956,7 @@ static_assert(BWD_STEP == 32 || BWD_STEP == 64, "entries per step");
 constexpr int LIST_PAD = 8;
 struct TileLds {
     float4 rec[BWD_STEP + 1][2];            // slot BWD_STEP: the all-zero record (v = 0: contributes nothing)
-    uint32_t list[4][BWD_STEP + LIST_PAD];  // byte offsets into rec
+    uint16_t list[4][BWD_STEP + LIST_PAD];  // byte offsets into rec (< 2 112)
 };
 constexpr uint32_t ZERO_REC_OFF = BWD_STEP * 32u;
 
@@ -1949,14 +1970,14 @@ __device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane, i
         const bool bit = gm >> g & 1u;
         const uint64_t m = __ballot(bit);
         rank[g] = lanes_below(m);
-        if (bit) lds.list[g][rank[g]] = (uint32_t)lane * 32u;
+        if (bit) lds.list[g][rank[g]] = (uint16_t)(lane * 32);
         cnt[g] = __builtin_popcountll(m);
         rows = cnt[g] > rows ? cnt[g] : rows;
     }
     rows = (rows + UNROLL - 1) / UNROLL * UNROLL;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        if (cnt[g] + lane < rows + UNROLL) lds.list[g][cnt[g] + lane] = ZERO_REC_OFF;   // + UNROLL: the prefetch
+        if (cnt[g] + lane < rows + UNROLL) lds.list[g][cnt[g] + lane] = (uint16_t)ZERO_REC_OFF;   // + UNROLL: the prefetch
     return rows;
 }
 
@@ -1971,11 +1992,15 @@ __device__ __forceinline__ int split_step(TileLds& lds, uint32_t gm, int lane, i
 // the caller's layout.  (LDS float atomics into a per-entry table took 44 LDS cycles per
 // instruction here: the kernel ran at the LDS's pace.)
 // ------------------------------------------------------------------------------------------
+// Round 4: the table holds HALF a step's list positions (BWD_HALF); the rows of a step are taken in two halves and an
+// entry's lane collects its rows of the table after each (registers), so that the step's LDS is 6.1 KB per wave instead
+// of 9.8 and SIX workgroups fit a CU where four did (the row arithmetic is what bounds the kernel).
+constexpr int BWD_HALF = BWD_STEP / 2;
 template <int NV>
 struct TileLdsBwd {
     static constexpr int S = NV <= 6 ? 6 : 8;        // floats per table row (8-byte aligned)
     TileLds t;
-    float sums[4][BWD_STEP + 4][S];                  // [group][list position]: reduced contributions
+    float sums[4][BWD_HALF + 4][S];                  // [group][list position - first of the half]: reduced contributions
 };
 
 // Row sums of FOUR wave-rows at once by a transposing fold.  Input: v[u][k], u = 0..3 (four consecutive
@@ -2031,15 +2056,15 @@ __device__ __forceinline__ void quad_sums(float* z) {
 
 // rows: a multiple of 4 (split_step<4> pads the lists with the all-zero record; the sums of such rows
 // land behind the lists' ends in the table and are never read)
-template <int C, int MASK>      // MASK: the mask of the arithmetic (a residual's: ORDR_AS)
+template <int C, int MASK>      // MASK: the mask of the arithmetic (a residual's: ORDR_AS); list rows r0 .. r0 + rows - 1
 __device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 2, C, MASK>& G,
-                                              TileLdsBwd<BwdLayout<2, C>::N>& lds, int rows, int lane) {
+                                              TileLdsBwd<BwdLayout<2, C>::N>& lds, int r0, int rows, int lane) {
     using BL = BwdLayout<2, C>;
     constexpr int NV = BL::N;
     constexpr int S = TileLdsBwd<NV>::S;
     const char* base = (const char*)&lds.t.rec[0][0];
     const int g = lane >> 4;
-    const uint32_t* lst = lds.t.list[g];
+    const uint16_t* lst = lds.t.list[g];
     const int bank = (lane >> 2) & 3;
     const int sigma = ((bank & 1) << 1) | (bank >> 1);      // {0, 2, 1, 3}: the list row whose sums this lane's bank ends up with
     const bool leader = (lane & 3) == 0;
@@ -2047,7 +2072,7 @@ __device__ __forceinline__ void backward_rows(const float* s, const Gsym<float, 
         float part[4][NV];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t off = lst[k0 + u];
+            const uint32_t off = lst[r0 + k0 + u];
             const Rec r = make_rec(*(const float4*)(base + off), *(const float4*)(base + off + 16));
 #pragma unroll
             for (int q = 0; q < NV; ++q) part[u][q] = 0.f;
@@ -2137,35 +2162,48 @@ __device__ __forceinline__ void load_tile_point(const SamplesView& sv, uint32_t 
     }
 }
 
-// The end of a step: every entry's rows of the sums table are added up and leave as atomics into gacc[j][8] (one
-// 32-byte row per sorted Gaussian).  Float atomics execute at the memory side, one request per 64-byte segment an
-// instruction touches (MI355X_MICROARCH.md, Global float atomics: full rate for 256 contiguous bytes, lanes in
-// different rows up to 17x slower), and the entries of a step come in runs of consecutive sorted indices (the list
-// build walks contiguous record ranges).  So an instruction takes EIGHT consecutive entries, lane = (entry, value):
-// eight 32-byte rows, mostly adjacent -- ~2.4x fewer segment requests than one instruction per value over all the
-// entries of the step (which touched every run once per value: round 3, gacc[8][N]).  A lane fetches its entry's
-// masks and table positions (packed into one word by the entry's lane) and its index with two lane shuffles.
+// After a half of a step's rows: this lane's entry adds its rows of the sums table (those whose list position lies in
+// the half that starts at r0).
 template <int NV>
-__device__ __forceinline__ void flush_step(const PlanView& pv, const TileLdsBwd<NV>& lds, uint32_t gm, uint32_t idx, const int* rank, int lane) {
+__device__ __forceinline__ void collect_rows(const TileLdsBwd<NV>& lds, uint32_t gm, const int* rank, int r0, float* esum) {
     constexpr int S = TileLdsBwd<NV>::S;
-    static_assert(BWD_STEP + 4 <= 128, "7 bits per table position");
-    uint32_t pk = gm & 15u;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pk |= ((uint32_t)rank[g] & 127u) << (4 + 7 * g);
-    const uint64_t live = __ballot((pk & 15u) != 0u);
+    for (int g = 0; g < 4; ++g) {
+        const int rr = rank[g] - r0;
+        if ((gm >> g & 1u) && rr >= 0 && rr < BWD_HALF) {
+            const float2* src = (const float2*)lds.sums[g][rr];
+#pragma unroll
+            for (int q = 0; q < S; q += 2) {
+                const float2 v = src[q / 2];
+                esum[q] += v.x; esum[q + 1] += v.y;
+            }
+        }
+    }
+}
+// The end of a step: every entry's sums leave as atomics into gacc[j][8] (one 32-byte row per sorted Gaussian).  Float
+// atomics execute at the memory side, one request per 64-byte segment an instruction touches (MI355X_MICROARCH.md,
+// Global float atomics: full rate for 256 contiguous bytes, lanes in different rows up to 17x slower), and the entries
+// of a step come in runs of consecutive sorted indices (the list build walks contiguous record ranges).  So an
+// instruction takes EIGHT consecutive entries, lane = (entry, value): eight 32-byte rows, mostly adjacent -- ~2.4x
+// fewer segment requests than one instruction per value over all the entries of the step (which touched every run
+// once per value: round 3, gacc[8][N]).  A lane fetches its (entry, value) from the entry's lane by shuffles.
+template <int NV>
+__device__ __forceinline__ void flush_entries(const PlanView& pv, uint32_t gm, uint32_t idx, const float* esum, int lane) {
+    const uint64_t live = __ballot((gm & 15u) != 0u);
     const int q = lane & 7, sub = lane >> 3;
-    const int qs = q < S ? q : 0;
 #pragma unroll 2
     for (int j = 0; j < BWD_STEP / 8; ++j) {
         if (((live >> (8 * j)) & 0xffull) == 0ull) continue;           // wave-uniform: none of these eight entries reaches the tile
         const int e = 8 * j + sub;
-        const uint32_t pe = (uint32_t)__shfl((int)pk, e), ie = (uint32_t)__shfl((int)idx, e);
+        const uint32_t ie = (uint32_t)__shfl((int)idx, e);
         float v = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (pe >> g & 1u) v += lds.sums[g][(pe >> (4 + 7 * g)) & 127u][qs];
+        for (int k = 0; k < NV; ++k) {
+            const float t = __shfl(esum[k], e);
+            v = q == k ? t : v;
+        }
 #ifndef PIGS_BWD_PROBE_NO_ATOMICS
-        if ((pe & 15u) != 0u && q < NV) atomicAdd(&pv.gacc[(size_t)ie * 8 + q], v);
+        if ((live >> e & 1ull) && q < NV) atomicAdd(&pv.gacc[(size_t)ie * 8 + q], v);
 #else
         if (v == 1.2345e-30f) pv.gacc[(size_t)ie * 8 + q] = v;      // keeps the sums alive, never stores
 #endif
@@ -2181,6 +2219,7 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
     constexpr int EM = MASK == ORDR ? ORDR_AS : MASK;      // a residual's backward = orders 0, 1, trace
     using BL = BwdLayout<2, C>;
     constexpr int NV = BL::N;
+    constexpr int S = TileLdsBwd<NV>::S;
     SPoint sp;
     bool valid;
     Gsym<float, 2, C, EM> G;
@@ -2224,11 +2263,18 @@ __device__ __forceinline__ void backward_tile(const PlanView& pv, const SamplesV
         int rank[4];
         const int rows = split_step<4>(lds.t, gm, lane, rank);
         wave_lds_fence();
+        float esum[S];                        // this lane's entry: the sums of its rows of the table
+#pragma unroll
+        for (int q = 0; q < S; ++q) esum[q] = 0.f;
+        for (int r0 = 0; r0 < rows; r0 += BWD_HALF) {        // (wave-uniform: at most two halves)
 #ifndef PIGS_BWD_PROBE_NO_ROWS            // probes of tools/ab_studies.sh: the kernel without its row arithmetic / its atomics
-        backward_rows<C, EM>(s, G, lds, rows, lane);
+            backward_rows<C, EM>(s, G, lds, r0, rows - r0 < BWD_HALF ? rows - r0 : BWD_HALF, lane);
 #endif
-        wave_lds_fence();
-        flush_step<NV>(pv, lds, have ? gm : 0u, idx, rank, lane);
+            wave_lds_fence();
+            collect_rows<NV>(lds, have ? gm : 0u, rank, r0, esum);
+            wave_lds_fence();
+        }
+        flush_entries<NV>(pv, have ? gm : 0u, idx, esum, lane);
     }, ranges_mask);
 }
 
@@ -2395,19 +2441,12 @@ __global__ __launch_bounds__(256, (bwd_waves<C, MASK>())) void block_backward_ke
             wave_lds_fence();
             const int rows = split_step<4>(lds.t, gm, lane, rank);
             wave_lds_fence();
-            backward_rows<C, EM>(s, G[tk], lds, rows, lane);
-            wave_lds_fence();
             any |= gm;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (gm >> g & 1u) {
-                    const float2* src = (const float2*)lds.sums[g][rank[g]];
-#pragma unroll
-                    for (int q = 0; q < S; q += 2) {
-                        const float2 v = src[q / 2];
-                        sum[q] += v.x; sum[q + 1] += v.y;
-                    }
-                }
+            for (int r0 = 0; r0 < rows; r0 += BWD_HALF) {
+                backward_rows<C, EM>(s, G[tk], lds, r0, rows - r0 < BWD_HALF ? rows - r0 : BWD_HALF, lane);
+                wave_lds_fence();
+                collect_rows<NV>(lds, gm, rank, r0, sum);
+                wave_lds_fence();
             }
         }
         if (have && any != 0u) {

@@ -227,3 +227,16 @@ def test_staged_outputs_and_gradients_match_the_direct_path(Sampler, orders):
         else:
             exp = want[o]
         assert rel(out, exp) < TOL, (o, rel(out, exp))
+
+
+def test_a_dense_patch_shares_its_bin_between_workgroups(Sampler):
+    """A clamped-normal cloud with a tight core (test_no_mlp.py:86 at scale): its central coarse bins hold tens of
+    thousands of points -- more than one workgroup's batch -- and are sorted by eight workgroups, each taking a slice of
+    the bin's cells and offsetting itself by the points it sees below its slice (samples_binsort_kernel).  Every point
+    and every gradient against the oracle; and the same cloud through the one-pass build."""
+    rng = np.random.default_rng(29)
+    means, con, values = random_gaussians(rng, 1500, 1, log_sigma_mean=-3.6, log_sigma_std=0.4)
+    pts = np.clip(rng.normal(0, 0.08, (150000, 2)), -1, 1)
+    for mode in ("unordered", "ordered"):
+        with forced_order(mode):
+            check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
