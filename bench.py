@@ -305,9 +305,12 @@ def main():
         else:
             # weak scaling (the grid shards by blocks of rows, the Gaussians are replicated):
             # the global grid is the square side x side grid over [-1,1]^2 with ~res*res points per GPU
-            # (side = round(res * sqrt(world)): 1024, 1448, 2048, 2896 for 1, 2, 4, 8 GPUs -- isotropic
-            # spacing at every N); rank r owns rows [r*rows, (r+1)*rows), rows = side // world
-            side_ = int(round(res * math.sqrt(world)))
+            # (side = res * sqrt(world) rounded to a multiple of 8 * world: 1024, 1456, 2048, 2880 for 1, 2, 4, 8 GPUs --
+            # isotropic spacing at every N, and every rank's block of rows is a lattice whose sides are multiples of 8,
+            # which the samples build takes in index-tiled order like the 1024 x 1024 grid of N = 1: per-GPU work stays
+            # the same KIND of work; points per GPU within 1.2 % of 1024^2, the exact count is in `config`);
+            # rank r owns rows [r*rows, (r+1)*rows), rows = side // world
+            side_ = max(1, int(round(res * math.sqrt(world) / (8 * world)))) * 8 * world
             r0, r1 = rank * (side_ // world), (rank + 1) * (side_ // world)
         pts_ = synthetic.grid_samples(side_, side_, row0=r0, rows=r1 - r0)
         return gs_, pts_, side_, r1 - r0

@@ -57,7 +57,7 @@ constexpr int PLAN_POINTS_PER_CELL = 16;   // target occupancy of a fine sample 
 // Per-workgroup partial bounding boxes of the sample points written by the first build kernel (plain
 // stores; same-address atomics serialise at ~10 ns each, so no atomics here) and reduced again by
 // every workgroup of the second.
-constexpr int PLAN_BBOX_BLOCKS = 256;
+constexpr int PLAN_BBOX_BLOCKS = 512;      // partials the samples workspace holds; the first launch has 256 or 512 workgroups
 
 // tile list entries: sorted Gaussian index | WIDE group mask << 24 | NARROW group mask << 28.  Two cut-offs
 // live in one plan: the forward evaluates a pair iff the q <= q_f ellipse reaches the point's group box

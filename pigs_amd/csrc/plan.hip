@@ -24,6 +24,7 @@
 #include "launch.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <mutex>
 #include <unordered_map>
 
@@ -106,6 +107,7 @@ struct BuildArgs {
     int do_samples, do_plan;
     int no_lookback;      // test hook: the scan's workgroups never publish; every look-back recomputes
     int zero_gacc;        // the backward's scratch is not known to be zero (a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN)
+    uint32_t bbox_blocks; // workgroups of the first launch = partials in sboxes / slat: 256, or 512 from 2^19 points on
 };
 
 __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
@@ -157,6 +159,7 @@ __device__ __forceinline__ void wave_box_from_rows_dpp(float& x0, float& x1, flo
 // while the search is still in flight, and is repeated only when the search finds another one.
 constexpr uint32_t BBOX_THREADS = 256;      // (1 024-thread workgroups -- 4 096 waves to launch -- cost small point sets ~3 us)
 constexpr uint32_t LAT_SEARCH0 = 2048, LAT_SEARCH1 = 16384;
+constexpr uint32_t BBOX_WIDE_POINTS = 1u << 19;
 __device__ __forceinline__ bool lattice_shape_ok(uint32_t rf, uint32_t n) {
     const uint32_t rs = rf ? n / rf : 0u;
     return rf >= 8u && (rf & 7u) == 0u && rs * rf == n && (rs & 7u) == 0u && n >= 64u;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     // the point above is then its own previous load (one extra load for the first of its rows), the point to the right
     // its neighbour lane's (one lane of the wave loads it) -- 9 + 1 loads where point, right and upper neighbour of
     // every pair were 24 (first launch 8.6 -> 6.x us at 1024^2).
-    constexpr int PB = 8;
-    auto pass = [&](uint32_t rf, bool box) {
+    auto pass = [&](auto pbc, uint32_t rf, bool box) {
+        constexpr int PB = decltype(pbc)::value;
         ax = ay = bx = by = 0.f;
         if (rf == 0u) {
             for (uint32_t i = blockIdx.x * BBOX_THREADS + tid; i < npair; i += PB * stride) {
@@ -264,7 +267,10 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     }
     // the pass on the remembered row length (or, without one, for the box alone)
     const uint32_t hf = search && lattice_shape_ok(a.rf_hint, n) ? a.rf_hint : 0u;
-    pass(hf, true);
+    // (from 2^19 points on, and with no row length expected, the launch has twice the workgroups and a thread half the
+    // rows: BuildArgs::bbox_blocks)
+    const bool wide = gridDim.x > 256u;
+    if (wide) pass(std::integral_constant<int, 4>{}, hf, true); else pass(std::integral_constant<int, 8>{}, hf, true);
     const uint32_t axis = fabsf(e1.y - e0.y) > fabsf(e1.x - e0.x) ? 1u : 0u;
     const float dir = (axis ? e1.y - e0.y : e1.x - e0.x) < 0.f ? -1.f : 1.f;
     auto backward = [&](float2 p, float2 r) { return (axis ? r.y - p.y : r.x - p.x) * dir < 0.f; };
@@ -291,7 +297,9 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     }
     const uint32_t rf = key == NONE ? 0u : key + 1u;
     const bool cand = lattice_shape_ok(rf, n);      // block-uniform
-    if (cand && rf != hf) pass(rf, false);          // first build of a size, or the points changed shape
+    if (cand && rf != hf) {                         // first build of a size, or the points changed shape
+        if (wide) pass(std::integral_constant<int, 4>{}, rf, false); else pass(std::integral_constant<int, 8>{}, rf, false);
+    }
     if (blockIdx.x == 0 && tid == 0) {
         a.sparams->lat_cand[0] = cand ? rf : 0u;
         a.sparams->lat_cand[1] = axis;
@@ -324,11 +332,17 @@ __global__ __launch_bounds__(256) void plan_zero_kernel(BuildArgs a) {
 // every workgroup of the count kernel reduces the PLAN_BBOX_BLOCKS partials (4 KB, L2 resident)
 // sbox[0..3] = the box; sbox[4..7] = the largest neighbour steps {along x, along y, across x, across y} (meaningful
 // when the first launch had a lattice candidate; a NaN partial cannot occur: the first launch turns it into +inf)
-__device__ __forceinline__ void reduce_boxes(const float4* boxes, const float4* lat, float* sbox, float (*sh)[8]) {
-    static_assert(PLAN_BBOX_BLOCKS == 256, "one partial per thread");
+__device__ __forceinline__ void reduce_boxes(const float4* boxes, const float4* lat, uint32_t nparts, float* sbox, float (*sh)[8]) {
+    static_assert(PLAN_BBOX_BLOCKS == 512, "one or two partials per thread");
     const float4 p = boxes[threadIdx.x];
     const float4 l = lat[threadIdx.x];
     float v[8] = {p.x, p.y, p.z, p.w, l.x, l.y, l.z, l.w};
+    if (nparts > 256u) {      // launch-uniform
+        const float4 p2 = boxes[256 + threadIdx.x];
+        const float4 l2 = lat[256 + threadIdx.x];
+        v[0] = fminf(v[0], p2.x); v[1] = fminf(v[1], p2.y); v[2] = fmaxf(v[2], p2.z); v[3] = fmaxf(v[3], p2.w);
+        v[4] = fmaxf(v[4], l2.x); v[5] = fmaxf(v[5], l2.y); v[6] = fmaxf(v[6], l2.z); v[7] = fmaxf(v[7], l2.w);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = (k & 2) || k >= 4 ? wave_max_bcast(v[k]) : wave_min_bcast(v[k]);
     const int wave = threadIdx.x >> 6;
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     float sbox[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool lattice = false;
     if (a.do_samples) {
-        reduce_boxes(a.sboxes, a.slat, sbox, shb);
+        reduce_boxes(a.sboxes, a.slat, a.bbox_blocks, sbox, shb);
         lattice = lattice_compact(sbox, lat_rf, lat_rf ? a.M / lat_rf : 0u, lat_axis);
     } else {      // the samples workspace is complete: its box is in its header
 #pragma unroll
@@ -2935,6 +2949,12 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     const bool coarse = do_samples && samples_take_coarse(s, order, stream);
     fill_samples_args(a, s, sws, samples, coarse);
     a.rf_hint = do_samples ? samples_rf_hint(s, stream) : 0u;
+    {
+        static const char* e = getenv("PIGS_BBOX_BLOCKS");      // (A/B: 256 | 512)
+        // same box, 1024^2 points: the plain pass 6.6 -> 5.9 us with 512 workgroups, the pass with a row length 7.5 -> 7.8
+        a.bbox_blocks = e ? (uint32_t)atoi(e) : (M >= (int64_t)BBOX_WIDE_POINTS && a.rf_hint == 0u ? 512u : 256u);
+        if (a.bbox_blocks != 512u) a.bbox_blocks = 256u;
+    }
     PlanLayout p{};
     if (do_plan) {
         if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
@@ -2946,7 +2966,7 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     }
     clear_hip_error();
     const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
-    if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(PLAN_BBOX_BLOCKS), dim3(BBOX_THREADS), 0, stream, a);
+    if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks), dim3(BBOX_THREADS), 0, stream, a);
     else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
     const uint32_t fused_blocks = gb > p.scan_blocks ? gb : p.scan_blocks;
     if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {

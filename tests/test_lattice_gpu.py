@@ -199,3 +199,28 @@ def test_points_that_stop_being_a_lattice_after_the_library_expected_one(Sampler
     for pts in (rng.uniform(-1, 1, g.shape), g[rng.permutation(g.shape[0])], g):
         s2 = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
         assert lattice_of(s2, hip_lib) == ((128, 64) if pts is g else (0, 0))
+
+
+@pytest.mark.parametrize("world,rank", [(2, 1), (8, 3)])
+def test_a_rank_s_rows_of_the_weak_scaling_grid_are_index_tiled(Sampler, hip_lib, world, rank):
+    """bench.py --gpus N (weak scaling): rank r's block of rows of the side x side grid, side a multiple of 8 N -- a
+    lattice with both sides multiples of 8, taken in index-tiled order by the library's own choice; a slice of it
+    against the oracle."""
+    import math
+    from oracle import c_oracle
+    from pigs_amd import synthetic
+    side = max(1, int(round(1024 * math.sqrt(world) / (8 * world)))) * 8 * world
+    rows = side // world
+    pts = synthetic.grid_samples(side, side, row0=rank * rows, rows=rows).float().cuda()
+    rng = np.random.default_rng(29)
+    means, con, values = random_gaussians(rng, 3000, 1, log_sigma_mean=-3.4, log_sigma_std=0.4)
+    t = [dev32(a) for a in (means, values, con)]
+    with lattice_env(None), torch.no_grad():
+        s = Sampler(False, backend="binned", fuse="all")
+        s.preprocess(t[0], t[1], None, t[2], pts)
+        outs = s.sample((0, 1, 2))
+    assert lattice_of(s, hip_lib) == (side, rows)
+    idx = torch.arange(0, pts.shape[0], 257, device="cuda")[:3000]
+    exp = c_oracle.forward(means, con, values, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
+    for o in range(3):
+        assert rel(outs[o][idx], exp[o]) < 1e-5
