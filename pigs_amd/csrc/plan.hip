@@ -18,6 +18,15 @@
 // Build-time knobs (defaults measured on MI355X): PIGS_FWD_WAVES, PIGS_FWD_UNROLL,
 // PIGS_GROUP_CAP, PIGS_BWD_WAVES, PIGS_BWD_STEP, PIGS_BWD_SPREAD, PIGS_LISTS_TPW, PIGS_TRAV_STEPS,
 // PIGS_XCD_CHUNK.
+#ifndef PIGS_FWD_STAGGER
+#define PIGS_FWD_STAGGER 0
+#endif
+#ifndef PIGS_FWD_STAGGER_PHASES
+#define PIGS_FWD_STAGGER_PHASES 2
+#endif
+#ifndef PIGS_FWD_STAGGER_FIRST
+#define PIGS_FWD_STAGGER_FIRST 2048
+#endif
 #include "pair_math.h"
 #include "plan.h"
 #include "grid_walk.h"
@@ -1914,6 +1923,16 @@ __global__ __launch_bounds__(64 * PIGS_FWD_WG_WAVES, (fwd_waves<C, MASK>())) voi
     }
     const uint32_t tile = xcd_block_chunk<PIGS_XCD_CHUNK * 4 / FW>(nmain, blockIdx.x - NHELP) * FW + (uint32_t)wave;
     if (tile >= sv.ntiles) return;
+#if PIGS_FWD_STAGGER
+    {   // experiment: the workgroups of the first generation start in phases, so that the launch's
+        // waves do not load, evaluate and store all at the same time.  Unit: s_sleep 32 = 2 048 cycles.
+        const uint32_t b = blockIdx.x - NHELP;
+        if (b < PIGS_FWD_STAGGER_FIRST) {
+            const uint32_t phase = ((b >> 3) ^ (b >> 8)) % PIGS_FWD_STAGGER_PHASES;
+            for (uint32_t k = 0; k < phase * PIGS_FWD_STAGGER; ++k) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+#endif
     forward_tile<C, MASK>(pv, sv, tile, lane, lds_all[wave], o0, o1, o2, o3, rz);
 }
 
