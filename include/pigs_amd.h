@@ -223,9 +223,8 @@ size_t pigs_plan_error_offset(void);
  * are index arithmetic: the build neither keys, counts, scans, scatters NOR COPIES the points -- and {0, 0} when
  * they were sorted into cells.  The decision is the build's own, on the device (the first backward step of the
  * fastest coordinate gives rf; the largest steps between index neighbours along and across rows bound every index
- * tile, which must stay within twice its share of the bounding box) for point sets of 262 144 points and more (below,
- * detecting the lattice costs more than sorting it); results never depend on it; PIGS_LATTICE=0 / 1 in the
- * environment: never / at every size.
+ * tile, which must stay within twice its share of the bounding box) for point sets of 4 096 points and more;
+ * results never depend on it; PIGS_LATTICE=0 / 1 in the environment: never / at every size.
  * CONTRACT that comes with it: a samples workspace in index-tiled order holds the ADDRESS of `samples`, not the
  * points; pigs_plan_build / pigs_plan_forward / pigs_plan_backward / pigs_residual_* read the caller's array
  * through it.  `samples` must therefore stay allocated and unmodified for as long as the samples workspace is

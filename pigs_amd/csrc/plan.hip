@@ -117,12 +117,22 @@ struct BuildArgs {
     int no_lookback;      // test hook: the scan's workgroups never publish; every look-back recomputes
     int zero_gacc;        // the backward's scratch is not known to be zero (a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN)
     uint32_t bbox_blocks; // workgroups of the first launch = partials in sboxes / slat: 256, or 512 from 2^19 points on
+    // round 4, "the Gaussians one launch ahead" (run_build): with a lattice expected and the box of the last build of this
+    // size known, the Gaussian chain does not wait for the first launch -- launch 1 = box of the samples || count of the
+    // Gaussians on the REMEMBERED box (grid domains steer the quality of the binning, never the result), launch 2 = scan
+    // of the Gaussian cells || the samples' lattice decision (and their count, should they be no lattice), launch 3 =
+    // scatter of the Gaussians (|| scan + scatter of the samples by scan_pick, should they be no lattice): one launch
+    // fewer in front of the tile lists.
+    int ahead;
+    float hint_box[4];
+    int s_scan_in_scatter;  // launch 3 of the chain above: no scan launch ran for the samples
 };
 
-__device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
+__device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words, uint32_t bid, uint32_t nb) {
     uint4* p4 = (uint4*)p;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words / 4; i += gridDim.x * blockDim.x) p4[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = bid * blockDim.x + threadIdx.x; i < words / 4; i += nb * blockDim.x) p4[i] = make_uint4(0, 0, 0, 0);
 }
+__device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) { zero_words(p, words, blockIdx.x, gridDim.x); }
 
 // Bounding boxes with the DPP modifier fused into the min / max (hipcc emits v_mov_dpp + a
 // canonicalising v_max + v_min per step from the builtin form: 4x the instructions).  The four
@@ -173,18 +183,25 @@ __device__ __forceinline__ bool lattice_shape_ok(uint32_t rf, uint32_t n) {
     const uint32_t rs = rf ? n / rf : 0u;
     return rf >= 8u && (rf & 7u) == 0u && rs * rf == n && (rs & 7u) == 0u && n >= 64u;
 }
+struct GaussLoad;
+__device__ __forceinline__ void gauss_count_ahead(const BuildArgs& a, uint32_t bid);
 __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     __shared__ float sh[4][8];
     __shared__ uint32_t shk[4];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    zero_words(a.szero, a.s_zero_words);
-    if (blockIdx.x == 0 && tid < 2) a.sparams->order_stat[tid] = 0u;
-    if (a.do_plan) {
-        zero_words(a.counts, a.zero_words);
-        if (a.zero_gacc) zero_words((uint32_t*)a.gacc, 8u * a.N);
-        if (blockIdx.x == 0 && tid < PLAN_BAR_WORDS) a.params->bar[tid] = 0u;
+    if (a.ahead && blockIdx.x >= a.bbox_blocks) {       // (block-uniform) the Gaussians one launch ahead, on the remembered box
+        gauss_count_ahead(a, blockIdx.x - a.bbox_blocks);
+        return;
     }
+    const uint32_t nblocks = a.bbox_blocks;             // (the launch may hold the Gaussians' workgroups behind these)
+    zero_words(a.szero, a.s_zero_words, blockIdx.x, nblocks);
+    if (blockIdx.x == 0 && tid < 2) a.sparams->order_stat[tid] = 0u;
+    if (a.do_plan && !a.ahead) {        // (ahead: a clean workspace, and its counters are being counted in this very launch)
+        zero_words(a.counts, a.zero_words, blockIdx.x, nblocks);
+        if (a.zero_gacc) zero_words((uint32_t*)a.gacc, 8u * a.N, blockIdx.x, nblocks);
+    }
+    if (a.do_plan && blockIdx.x == 0 && tid < PLAN_BAR_WORDS) a.params->bar[tid] = 0u;
     const float INF = __builtin_huge_valf();
     float x0 = INF, y0 = INF, x1 = -INF, y1 = -INF;
     auto take = [&](float x, float y) {
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     const float4* pts2 = (const float4*)a.samples;
     const uint32_t n = a.M;
     const uint32_t npair = n / 2;                 // float4 = two points
-    const uint32_t stride = gridDim.x * BBOX_THREADS;
+    const uint32_t stride = nblocks * BBOX_THREADS;
     // the largest neighbour steps (NaN / inf coordinates: +inf, never compact)
     float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
     auto step = [&](float& s, float u, float v) {
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     const uint32_t hf = search && lattice_shape_ok(a.rf_hint, n) ? a.rf_hint : 0u;
     // (from 2^19 points on, and with no row length expected, the launch has twice the workgroups and a thread half the
     // rows: BuildArgs::bbox_blocks)
-    const bool wide = gridDim.x > 256u;
+    const bool wide = nblocks > 256u;
     if (wide) pass(std::integral_constant<int, 4>{}, hf, true); else pass(std::integral_constant<int, 8>{}, hf, true);
     const uint32_t axis = fabsf(e1.y - e0.y) > fabsf(e1.x - e0.x) ? 1u : 0u;
     const float dir = (axis ? e1.y - e0.y : e1.x - e0.x) < 0.f ? -1.f : 1.f;
@@ -399,18 +416,83 @@ __device__ __forceinline__ Run run_of(uint32_t k, int lane) {
 // as column w of the (bin, workgroup) matrix; a point keeps {fine cell, rank in (bin, workgroup)}.
 __device__ __forceinline__ void samples_hist_part(const BuildArgs& a, uint32_t w, const SampleGrid& sg, uint32_t* lh, int lane);
 
+// The Gaussians' half of the count: cell key (level by size, cell by centre) and rank of every Gaussian.  `box`: the
+// samples' bounding box the grid's domain is laid over -- of this build, or (BuildArgs::ahead) of the last one.
+struct GaussLoad { float m[2], c[3]; };
+__device__ __forceinline__ GaussLoad gauss_count_load(const BuildArgs& a, uint32_t bid) {      // (issued early: flies while the box is reduced)
+    GaussLoad ld = {{0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const uint32_t i = bid * 256 + threadIdx.x;
+    if (i < a.N) {
+        ld.m[0] = a.means[2 * i]; ld.m[1] = a.means[2 * i + 1];
+        ld.c[0] = a.conics[3 * i]; ld.c[1] = a.conics[3 * i + 1]; ld.c[2] = a.conics[3 * i + 2];
+    }
+    return ld;
+}
+__device__ __forceinline__ void gauss_count_part(const BuildArgs& a, uint32_t bid, const float* box, const GaussLoad& ld) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = bid * 256 + threadIdx.x;
+    const bool valid = i < a.N;
+    const float* gm = ld.m;
+    const float* gc = ld.c;
+    const GaussGrid g = gauss_grid(box, a.G0);
+    if (bid == 0 && threadIdx.x == 0) {
+        a.params->gg = g;
+        a.params->scan_error = 0;
+        a.params->q_f = a.q_f;
+        a.params->q_b = a.q_b;
+        a.params->n_points = 0u;
+#pragma unroll
+        for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
+    }
+    uint32_t key = 0xffffffffu;
+    int l = 0;
+    if (valid) {
+        const float mx = gm[0], my = gm[1];
+        const float ca = gc[0], cb = gc[1], cc = gc[2];
+        // half extents of the q <= q_max ellipse: sqrt(q_max * Sigma_xx), Sigma = C^-1
+        const float det = ca * cc - cb * cb;
+        const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
+        float s = g.s0;
+        while (l < a.L - 1 && !(R <= s)) { ++l; s *= 2.f; }
+        const int G = a.G0 >> l;
+        const float inv_s = 1.f / s;
+        const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
+        const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
+        key = a.level_off[l] + ((uint32_t)(cy * G + cx) << level_shift((uint32_t)(G * G)));
+    }
+    const Run r = run_of(key, lane);
+    uint32_t base = 0;
+    if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
+    base = __shfl(base, r.start);
+    if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
+}
+
+__device__ __forceinline__ void gauss_count_ahead(const BuildArgs& a, uint32_t bid) {
+    gauss_count_part(a, bid, a.hint_box, gauss_count_load(a, bid));
+}
+
+template <bool COH>
+__device__ __forceinline__ void scan_block(const BuildArgs& a, bool seg0, uint32_t b, uint32_t* sh, uint32_t* sh2);
+
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     __shared__ float shb[4][8];
     __shared__ uint32_t lh[SAMPLES_COARSE_BINS];
+    __shared__ uint32_t scan_sh[4], scan_sh2[4];
     const int lane = threadIdx.x & 63;
+    // BuildArgs::ahead: the Gaussians were counted in the first launch -- the first workgroups of THIS one scan their
+    // cells (look-back among the launch's first workgroups, as in plan_scan_kernel), the samples' workgroups follow
+    const uint32_t shift = a.ahead ? a.scan_blocks : 0u;
+    if (blockIdx.x < shift) {                            // block-uniform
+        scan_block<false>(a, true, blockIdx.x, scan_sh, scan_sh2);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - shift, nb = gridDim.x - shift;
     // Every dependent memory round trip costs 2-4 us in this kernel (in-kernel stamps): issue the
     // workgroup's own loads first, so they fly while the bounding-box partials are reduced.
-    const uint32_t gblocks = a.do_plan ? (a.N + 255) / 256 : 0;
-    const bool gpart = blockIdx.x < gblocks;
-    float gm[2] = {0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f};
+    const uint32_t gblocks = a.do_plan && !a.ahead ? (a.N + 255) / 256 : 0;
+    const bool gpart = bid < gblocks;
     float2 pt[4];
-    const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
-    uint32_t i0 = ((blockIdx.x - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
+    uint32_t i0 = ((bid - gblocks) * 4 + (threadIdx.x >> 6)) * 256 + lane;
     // the first launch's lattice candidate (plan.h): with one, the sample workgroups most likely have nothing to do
     const uint32_t lat_rf = a.do_samples ? a.sparams->lat_cand[0] : 0u;
     const uint32_t lat_axis = a.do_samples ? a.sparams->lat_cand[1] : 0u;
@@ -421,14 +503,9 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             pt[k] = i < a.M ? ((const float2*)a.samples)[i] : make_float2(0.f, 0.f);
         }
     };
-    if (gpart) {
-        if (gi < a.N) {
-            gm[0] = a.means[2 * gi]; gm[1] = a.means[2 * gi + 1];
-            gc[0] = a.conics[3 * gi]; gc[1] = a.conics[3 * gi + 1]; gc[2] = a.conics[3 * gi + 2];
-        }
-    } else if (!a.coarse && lat_rf == 0u) {
-        load_points();
-    }
+    GaussLoad gld = {{0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (gpart) gld = gauss_count_load(a, bid);
+    else if (!a.coarse && lat_rf == 0u) load_points();
     float sbox[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bool lattice = false;
     if (a.do_samples) {
@@ -438,64 +515,30 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) sbox[k] = a.sparams->box[k];
     }
-    const GaussGrid g = gauss_grid(sbox, a.G0);
     const SampleGrid sg = sample_grid(sbox, a.M, a.scells_cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (a.do_samples) {
+    if (bid == gblocks && threadIdx.x == 0 && a.do_samples) {      // (the first of the samples' workgroups)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a.sparams->box[k] = sbox[k];
-            a.sparams->sg = sg;
-            a.sparams->scan_error = 0;
-            a.sparams->lat[0] = lattice ? lat_rf : 0u;
-            a.sparams->lat[1] = lattice ? a.M / lat_rf : 0u;
-            a.sparams->src = lattice ? (uint64_t)(uintptr_t)a.samples : 0ull;
-        }
-        if (a.do_plan) {
-            a.params->gg = g;
-            a.params->scan_error = 0;
-            a.params->q_f = a.q_f;
-            a.params->q_b = a.q_b;
-            a.params->n_points = 0u;
-#pragma unroll
-            for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
-        }
+        for (int k = 0; k < 4; ++k) a.sparams->box[k] = sbox[k];
+        a.sparams->sg = sg;
+        a.sparams->scan_error = 0;
+        a.sparams->lat[0] = lattice ? lat_rf : 0u;
+        a.sparams->lat[1] = lattice ? a.M / lat_rf : 0u;
+        a.sparams->src = lattice ? (uint64_t)(uintptr_t)a.samples : 0ull;
     }
     // Gaussian workgroups first, sample workgroups after them: the two halves are independent
     // latency chains (load -> returning atomic -> store) and run concurrently on different CUs
     if (gpart) {                        // block-uniform: whole waves enter
-        const uint32_t i = gi;
-        const bool valid = i < a.N;
-        uint32_t key = 0xffffffffu;
-        int l = 0;
-        if (valid) {
-            const float mx = gm[0], my = gm[1];
-            const float ca = gc[0], cb = gc[1], cc = gc[2];
-            // half extents of the q <= q_max ellipse: sqrt(q_max * Sigma_xx), Sigma = C^-1
-            const float det = ca * cc - cb * cb;
-            const float R = sqrtf(a.q_max * fmaxf(ca, cc) / det);   // NaN / inf (degenerate conic) -> top level
-            float s = g.s0;
-            while (l < a.L - 1 && !(R <= s)) { ++l; s *= 2.f; }
-            const int G = a.G0 >> l;
-            const float inv_s = 1.f / s;
-            const int cx = (int)clampf((mx - g.ox) * inv_s, 0.f, (float)(G - 1));   // NaN -> 0
-            const int cy = (int)clampf((my - g.oy) * inv_s, 0.f, (float)(G - 1));
-            key = a.level_off[l] + ((uint32_t)(cy * G + cx) << level_shift((uint32_t)(G * G)));
-        }
-        const Run r = run_of(key, lane);
-        uint32_t base = 0;
-        if (r.leader && valid) base = atomicAdd(&a.counts[key], r.len);
-        base = __shfl(base, r.start);
-        if (valid) a.gkey[i] = make_uint2(key, base + (uint32_t)(lane - r.start));
+        gauss_count_part(a, bid, sbox, gld);
     } else if (lattice) {
         // index-tiled: nothing to key, count or move (block-uniform)
     } else if (a.coarse) {
-        samples_hist_part(a, blockIdx.x - gblocks, sg, lh, lane);
+        samples_hist_part(a, bid - gblocks, sg, lh, lane);
     } else
     // the one-pass count: a sample workgroup takes 1 024 points at a time -- one block where the launch has a workgroup
     // per block; where the host expected a lattice (rf_hint) and launched an eighth of them, the workgroups stride
     // over the blocks: the points that were no lattice after all are still all counted, by fewer hands
-    for (uint32_t sb = blockIdx.x - gblocks; sb < a.s_blocks; sb += gridDim.x - gblocks) {
-        const bool first = sb == blockIdx.x - gblocks;
+    for (uint32_t sb = bid - gblocks; sb < a.s_blocks; sb += nb - gblocks) {
+        const bool first = sb == bid - gblocks;
         i0 = (sb * 4 + (threadIdx.x >> 6)) * 256 + lane;
         if (!first || lat_rf != 0u) load_points();      // (the first block's loads were issued early unless a lattice candidate stood)
         // each wave: 4 steps of 64 consecutive points, their atomics issued back to back
@@ -736,8 +779,49 @@ __device__ __forceinline__ void samples_scatter_part(const BuildArgs& a, uint32_
     }
 }
 
+// A workgroup scans ALL `nblocks` blocks of 1 024 counters itself, a block at a time through LDS (the counters are
+// final: the count launch has completed), and every thread picks the start of ITS key out of the block that holds
+// it.  ~0.7 us per block and workgroup: the slow way round, taken by the samples' workgroups of launch 3 of
+// BuildArgs::ahead when the points they expected to be a lattice are none (the memory then turns around).  (As a
+// replacement of the Gaussians' scan launch it was measured: 43 blocks, scatter 5.4 -> 28.9 us)
+__device__ __forceinline__ uint32_t scan_pick(const uint32_t* counts, uint32_t nblocks, uint32_t key, uint32_t* lds, uint32_t* ws) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0, mine = 0;
+    for (uint32_t c0 = 0; c0 < nblocks; c0 += 8u) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = c0 + (uint32_t)k < nblocks ? ((const uint4*)counts)[(size_t)(c0 + (uint32_t)k) * 256 + threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t c = c0 + (uint32_t)k;
+            if (c >= nblocks) break;                       // block-uniform
+            const uint32_t sum = v[k].x + v[k].y + v[k].z + v[k].w;
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) ws[wave] = inc;
+            __syncthreads();
+            uint32_t base = carry + inc - sum;
+            for (int w = 0; w < wave; ++w) base += ws[w];
+            const uint32_t tot = ws[0] + ws[1] + ws[2] + ws[3];
+            ((uint4*)lds)[threadIdx.x] = make_uint4(base, base + v[k].x, base + v[k].x + v[k].y, base + v[k].x + v[k].y + v[k].z);
+            __syncthreads();
+            if ((key >> 10) == c) mine = lds[key & 1023u];
+            carry += tot;
+            __syncthreads();                               // lds / ws are the next block's
+        }
+    }
+    return mine;
+}
+
 __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     extern __shared__ uint4 scatter_stage[];      // coarse-bin path with a chunk that fits: [h_chunk] records + 2 x 256 words
+    __shared__ uint32_t scan_lds[PLAN_SCAN_BLOCK];
+    __shared__ uint32_t scan_ws[4];
     const uint32_t gblocks = a.do_plan ? (a.N + 255) / 256 : 0;
     const bool gpart = blockIdx.x < gblocks;
     const uint32_t i = (gpart ? blockIdx.x : blockIdx.x - gblocks) * 256 + threadIdx.x;
@@ -786,10 +870,19 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         // launch of a build into a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN, re-zeroed by plan_unpermute_kernel
         // behind every backward: no memset launch, and no 8 scattered stores per Gaussian here either)
     }
+    uint32_t sstart = 0;
+    if (!gpart && a.s_scan_in_scatter) {      // block-uniform: an expected lattice that was none, and no scan launch ran
+        const uint2 kr = i < a.M ? a.skey[i] : make_uint2(0xffffffffu, 0u);
+        sstart = scan_pick(a.scounts, a.s_scan_blocks, kr.x, scan_lds, scan_ws);
+    }
     if (!gpart && i < a.M) {
         const uint2 kr = a.skey[i];
         const float2 p = ((const float2*)a.samples)[i];
-        if (a.coarse) {
+        if (a.s_scan_in_scatter) {
+            SPoint sp;
+            sp.x = p.x; sp.y = p.y; sp.m = i;
+            a.spts[sstart + kr.y] = sp;
+        } else if (a.coarse) {
             // coarse-bin path: to the point's bin segment of the temporary array, behind the points that earlier
             // workgroups (chunks) sent to this bin; the fine cell travels along
             const uint32_t w = i / a.h_chunk, bin = kr.x / a.cells_per_bin;
@@ -2625,15 +2718,16 @@ size_t plan_workspace_bytes(int64_t N, int64_t M, int c) {
     return make_plan_layout(N, M, c).total_bytes;
 }
 
-constexpr int64_t LATTICE_MIN_POINTS = 1 << 18;
+constexpr int64_t LATTICE_MIN_POINTS = 1 << 12;
 static void fill_samples_args(BuildArgs& a, const SamplesLayout& s, void* sws, const void* samples, bool coarse) {
     char* b = (char*)sws;
     a.sparams = (SampleParams*)(b + s.off_params);
     a.sboxes = (float4*)(b + s.off_boxes);
     a.slat = (float4*)(b + s.off_lat);
-    {   // index-tiled order: from LATTICE_MIN_POINTS points on (below, what the sort of a lattice costs -- ~1 us of the count
-        // and scatter launches per 131 072 points -- is less than the ~2.5 us its detection adds to the first launch:
-        // 256^2 grid, cold step 52.3 us index-tiled against 49.5 sorted); PIGS_LATTICE=1 / 0: always / never
+    {   // index-tiled order: from LATTICE_MIN_POINTS points on.  (Until the Gaussians ran one launch ahead -- BuildArgs::ahead
+        // -- the bar stood at 2^18 points: detecting a lattice adds ~2.5 us to the first launch, sorting one costs ~1 us of
+        // the count and scatter launches per 131 072 points.  A lattice that is expected now saves a whole launch: 128^2 ...
+        // 384^2 grids, cold step -4 ... -5 us; BASELINE configs[1] 34.1 -> 31.5 us.)  PIGS_LATTICE=1 / 0: always / never
         const char* e = getenv("PIGS_LATTICE");
         a.no_lattice = e ? e[0] == '0' : s.M < LATTICE_MIN_POINTS;
     }
@@ -2687,10 +2781,16 @@ struct OrderHint {
     uint32_t builds = 0;           // samples builds of this (device, M) so far: the statistic is asked for after the first
                                    // two and after every 16th (the 8-byte copy is a 4 us blit in the build's stream)
     hipEvent_t ev = nullptr;
-    uint32_t* host = nullptr;      // pinned {runs, points, lat_cand[2], lat[2]}: SampleParams from order_stat on
+    uint32_t* host = nullptr;      // pinned: the first 64 bytes of SampleParams (box, grid, order_stat, lat_cand, lat)
     uint32_t rf = 0;               // the row length of the last completed build when it took the index-tiled order (else 0)
+    float box[4] = {0.f, 0.f, 0.f, 0.f};   // the samples' bounding box of the last completed build
+    bool box_seen = false;         // ... and whether the completed build before it had the same one: a box to build the
+    bool box_stable = false;       //     Gaussians' grid on before this build's own is known (BuildArgs::ahead)
     uint64_t stamp = 0;
 };
+constexpr uint32_t HINT_WORDS = 16;
+static_assert(offsetof(SampleParams, box) == 0 && offsetof(SampleParams, order_stat) == 40 && offsetof(SampleParams, lat) == 56,
+              "the hint copy: the first 64 bytes of SampleParams");
 static std::mutex g_hint_mu;
 static OrderHint g_hints[16];
 static uint64_t g_hint_clock = 0;
@@ -2717,8 +2817,9 @@ static OrderHint* hint_entry(int device, int64_t M, bool create) {      // g_hin
         lru->ev = nullptr;
     }
     if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
-    if (!lru->host && hipHostMalloc((void**)&lru->host, 6 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (!lru->host && hipHostMalloc((void**)&lru->host, HINT_WORDS * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
     lru->device = device; lru->M = M; lru->coarse = false; lru->pending = false; lru->builds = 0; lru->rf = 0; lru->stamp = ++g_hint_clock;
+    lru->box_seen = lru->box_stable = false;
     return lru;
 }
 
@@ -2734,9 +2835,15 @@ static void hint_poll(OrderHint& h) {           // g_hint_mu held
     (void)hipGetLastError();          // hipErrorNotReady is an answer, not a failure
     if (q == hipSuccess) {
         h.pending = false;
-        h.rf = h.host[4];          // SampleParams::lat[0]
+        h.rf = h.host[14];         // SampleParams::lat[0]
         if (h.rf != 0u) h.coarse = false;      // index-tiled: the points arrived in order (and left no run statistic)
-        else if (h.host[1] > 0u) h.coarse = (uint64_t)h.host[0] * 100u > (uint64_t)h.host[1] * 55u;
+        else if (h.host[11] > 0u) h.coarse = (uint64_t)h.host[10] * 100u > (uint64_t)h.host[11] * 55u;
+        float b[4];
+        memcpy(b, h.host, sizeof(b));
+        const bool finite = fabsf(b[0]) < 3.0e38f && fabsf(b[1]) < 3.0e38f && fabsf(b[2]) < 3.0e38f && fabsf(b[3]) < 3.0e38f && b[2] > b[0] && b[3] > b[1];
+        h.box_stable = finite && h.box_seen && memcmp(b, h.box, sizeof(b)) == 0;
+        h.box_seen = finite;
+        memcpy(h.box, b, sizeof(b));
     }
 }
 // order: 0 = ask the memory, 1 = one pass, 2 = coarse bins
@@ -2758,13 +2865,16 @@ static bool samples_take_coarse(const SamplesLayout& s, int order, hipStream_t s
 }
 
 // the row length the last completed build of M points found (index-tiled order), or 0
-static uint32_t samples_rf_hint(const SamplesLayout& s, hipStream_t stream) {
+// *box_ok / box: the same box in the last two completed builds
+static uint32_t samples_rf_hint(const SamplesLayout& s, hipStream_t stream, bool* box_ok = nullptr, float* box = nullptr) {
+    if (box_ok) *box_ok = false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0u; }
     std::lock_guard<std::mutex> lock(g_hint_mu);
     OrderHint* h = hint_entry(dev, s.M, false);
     if (!h) return 0u;
     if (!stream_capturing(stream)) hint_poll(*h);
+    if (box_ok && box && h->box_stable) { *box_ok = true; memcpy(box, h->box, 4 * sizeof(float)); }
     return h->rf;
 }
 
@@ -2778,10 +2888,11 @@ static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t st
     OrderHint* h = hint_entry(dev, s.M, true);
     if (!h) return;
     const uint32_t nth = h->builds++;
-    if (h->pending || (nth >= 2u && (nth & 15u) != 0u)) return;
+    // (with a row length in the memory the build runs on expectations -- an eighth of the count's workgroups, the
+    // Gaussians one launch ahead -- and a point set that stopped meeting them should not be met 15 more times)
+    if (h->pending || (nth >= 2u && (nth & (h->rf ? 3u : 15u)) != 0u)) return;
     const SampleParams* sp = (const SampleParams*)((const char*)sws + s.off_params);
-    static_assert(offsetof(SampleParams, lat) == offsetof(SampleParams, order_stat) + 4 * sizeof(uint32_t), "one copy: order_stat, lat_cand, lat");
-    if (hipMemcpyAsync(h->host, sp->order_stat, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+    if (hipMemcpyAsync(h->host, sp, HINT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
         h->pending = true;
     (void)hipGetLastError();
@@ -2967,7 +3078,8 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     a.zero_gacc = !plan_ws_clean;
     const bool coarse = do_samples && samples_take_coarse(s, order, stream);
     fill_samples_args(a, s, sws, samples, coarse);
-    a.rf_hint = do_samples ? samples_rf_hint(s, stream) : 0u;
+    bool box_ok = false;
+    a.rf_hint = do_samples ? samples_rf_hint(s, stream, &box_ok, a.hint_box) : 0u;
     {
         static const char* e = getenv("PIGS_BBOX_BLOCKS");      // (A/B: 256 | 512)
         // same box, 1024^2 points: the plain pass 6.6 -> 5.9 us with 512 workgroups, the pass with a row length 7.5 -> 7.8
@@ -2985,10 +3097,24 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     }
     clear_hip_error();
     const uint32_t gb = do_plan ? (uint32_t)((N + 255) / 256) : 0u;
+    // The Gaussians one launch ahead (BuildArgs::ahead): a lattice is expected, the samples' box was the same in the last
+    // two completed builds of this size, the plan workspace's counters are zero.
+    static const bool no_ahead = getenv("PIGS_NO_AHEAD") != nullptr;
+    const bool ahead = do_samples && do_plan && plan_ws_clean && !coarse && !no_lookback && !PIGS_FUSED_BUILD && !no_ahead &&
+                       a.rf_hint != 0u && !a.no_lattice && box_ok && s.scan_blocks <= 1024u;
+    a.ahead = ahead; a.s_scan_in_scatter = ahead;
+    if (ahead) {
+        a.s_blocks = (uint32_t)((M + 1023) / 1024);
+        hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks + gb), dim3(BBOX_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(plan_count_kernel, dim3(p.scan_blocks + (a.s_blocks + 7u) / 8u), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (uint32_t)((M + 255) / 256)), dim3(256), 0, stream, a);
+    } else
     if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks), dim3(BBOX_THREADS), 0, stream, a);
     else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
     const uint32_t fused_blocks = gb > p.scan_blocks ? gb : p.scan_blocks;
-    if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {
+    if (ahead) {
+        // (launched above)
+    } else if (do_plan && !do_samples && !no_lookback && fused_blocks <= FUSED_BUILD_MAX_BLOCKS && PIGS_FUSED_BUILD) {
         hipLaunchKernelGGL(plan_gauss_build_kernel, dim3(fused_blocks), dim3(256), 0, stream, a);
     } else {
         // a lattice expected (the row length of the last build of this size): an eighth of the one-pass count's workgroups

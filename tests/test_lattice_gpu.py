@@ -76,7 +76,7 @@ CASES = [
 def test_lattices_are_index_tiled_and_match_the_oracle(Sampler, hip_lib, name, pts, want):
     rng = np.random.default_rng(7)
     means, con, values = random_gaussians(rng, 600, 1, log_sigma_mean=-2.6, log_sigma_std=0.5)
-    with lattice_env("1"):           # (without the variable the index-tiled order starts at 2^18 points)
+    with lattice_env("1"):           # (without the variable the index-tiled order starts at 2^12 points)
         s = check_case(Sampler, means, con, values, pts, orders=(0, 1, 2), gtol="bound")
         assert lattice_of(s, hip_lib) == want
     with lattice_env("0"):
@@ -144,15 +144,15 @@ def test_index_tiled_samples_are_reused_and_survive_new_gaussians(Sampler, hip_l
             first = s._plan.samples
         assert s._plan.samples is first and lattice_of(s, hip_lib) == (96, 64)
         outs = s.sample((0, 1, 2))
-        exp = c_oracle.forward(means, con, values, pts.cpu().double().numpy(), orders=(0, 1, 2))
+        exp = c_oracle.forward(*[x.cpu().double().numpy() for x in (t[0], t[2], t[1])], pts.cpu().double().numpy(), orders=(0, 1, 2))
         for o in range(3):
             assert rel(outs[o], exp[o]) < 1e-5
 
 
 def test_bench_grid_is_index_tiled_and_equals_the_sorted_build(Sampler, hip_lib):
     """C3's own points (1024^2 grid, 65 536 lattice Gaussians, kappa 0.5; the library's own choice: index-tiled from
-    2^18 points): index-tiled and sorted builds evaluate the same pairs up to the order inside a tile; a slice against
-    the oracle.  And a 256^2 grid is sorted unless asked otherwise."""
+    2^12 points): index-tiled and sorted builds evaluate the same pairs up to the order inside a tile; a slice against
+    the oracle.  BASELINE configs[1]'s 256^2 grid is index-tiled too, a 56 x 56 grid is sorted unless asked otherwise."""
     from oracle import c_oracle
     from pigs_amd import synthetic
     gs = synthetic.lattice_gaussians(256, 256, 0.5, seed=0)
@@ -176,6 +176,9 @@ def test_bench_grid_is_index_tiled_and_equals_the_sorted_build(Sampler, hip_lib)
     with lattice_env(None), torch.no_grad():
         s = Sampler(False, backend="binned")
         s.preprocess(t["means"], t["values"], None, t["conics"], synthetic.grid_samples(256).float().cuda())
+        s.sample_gaussians()
+        assert lattice_of(s, hip_lib) == (256, 256)
+        s.preprocess(t["means"], t["values"], None, t["conics"], synthetic.grid_samples(56).float().cuda())
         s.sample_gaussians()
         assert lattice_of(s, hip_lib) == (0, 0)
 
@@ -221,6 +224,44 @@ def test_a_rank_s_rows_of_the_weak_scaling_grid_are_index_tiled(Sampler, hip_lib
         outs = s.sample((0, 1, 2))
     assert lattice_of(s, hip_lib) == (side, rows)
     idx = torch.arange(0, pts.shape[0], 257, device="cuda")[:3000]
-    exp = c_oracle.forward(means, con, values, pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
+    exp = c_oracle.forward(*[x.cpu().double().numpy() for x in (t[0], t[2], t[1])], pts[idx].cpu().double().numpy(), orders=(0, 1, 2))
     for o in range(3):
         assert rel(outs[o][idx], exp[o]) < 1e-5
+
+
+def test_gaussians_one_launch_ahead_and_points_that_break_the_expectation(Sampler, hip_lib, monkeypatch):
+    """With a lattice expected and the same bounding box in the last two completed builds of a size, the Gaussians are
+    binned on the REMEMBERED box in the launch that looks at the points (plan.hip, BuildArgs::ahead): three launches
+    in front of the tile lists instead of four.  Results must not depend on it -- not when the Gaussians change, not
+    when the next point set of that size lies elsewhere (the Gaussians' grid then covers the wrong domain: slower,
+    never wrong), not when it is no lattice at all (its workgroups scan and scatter in the third launch)."""
+    from oracle import c_oracle
+    monkeypatch.setenv("PIGS_LATTICE", "1")
+    rng = np.random.default_rng(31)
+    g = grid(96, 64)
+    s = Sampler(False, backend="binned", fuse="all", reuse_samples=False)
+
+    def run(points, lo=-1.0, hi=1.0, n=700):
+        means, con, values = random_gaussians(rng, n, 1, log_sigma_mean=-2.8, log_sigma_std=0.4, lo=lo, hi=hi)
+        t = [dev32(a) for a in (means, values, con)]
+        points = points.astype(np.float32).astype(np.float64)      # (the oracle sees the coordinates the device sees)
+        p = dev32(points)
+        with torch.no_grad():
+            s.preprocess(t[0], t[1], None, t[2], p)
+            outs = s.sample((0, 1, 2))
+        torch.cuda.synchronize()
+        exp = c_oracle.forward(*[x.cpu().double().numpy() for x in (t[0], t[2], t[1])], points, orders=(0, 1, 2))      # (the inputs the device saw)
+        for o in range(3):
+            assert rel(outs[o], exp[o]) < 1e-5, (o, rel(outs[o], exp[o]))
+        return lattice_of(s, hip_lib)
+
+    for _ in range(6):                      # the memory fills, the plan workspaces are recycled ones: ahead from here on
+        assert run(g) == (96, 64)
+    assert run(g * 0.5 + 3.0, lo=2.5, hi=3.5) == (96, 64)      # the same lattice somewhere else: the remembered box is wrong
+    assert run(g) == (96, 64)
+    assert run(rng.uniform(-1, 1, g.shape)) == (0, 0)           # no lattice: the fall-back of the third launch
+    assert run(g[rng.permutation(g.shape[0])]) == (0, 0)
+    for _ in range(5):
+        run(rng.uniform(-1, 1, g.shape))                        # ... until the memory has turned around
+    for _ in range(6):
+        assert run(g) == (96, 64)                               # and back

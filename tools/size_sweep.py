@@ -10,7 +10,7 @@ from diff_gaussian_sampling import GaussianSampler
 gs = synthetic.lattice_gaussians(256, 256, 0.5)
 t = {k: v.float().cuda() for k, v in gs.items()}
 NSTEP = 50
-for res in (512, 1024, 2048, 4096):
+for res in ([int(x) for x in sys.argv[1:]] or (512, 1024, 2048, 4096)):
     pts = synthetic.grid_samples(res).float().cuda()
     s = GaussianSampler(False, fuse="all", reuse_samples=False)        # cold steps, as the bench's headline
     with torch.no_grad():
