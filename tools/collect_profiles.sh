@@ -72,6 +72,9 @@ if [ $part = lines ] || [ $part = all ]; then
     for c in grid random; do python3 tools/preprocess_cases.py $c 1.3 2>&1 | grep kappa; done >> $out/${tag}_point_orders.txt
     (cd tools/ubench && ./atomics3; ./atomics4) > $out/${tag}_atomics_ubench.txt 2>&1
     python3 tools/aggregate_lists_probe.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_aggregate_lists_probe.txt
+    # the deferred tile lists against the default, every kind of step, same process (C3; BASELINE configs[1]'s sizes; kappa 1.3)
+    (python3 tools/ab_defer.py 0.5 2>&1 | grep defer; python3 tools/ab_defer.py 0.5 90 256 2>&1 | grep defer | sed "s/^/c2 sizes: /"; \
+     python3 tools/ab_defer.py 1.3 2>&1 | grep defer | sed "s/^/kappa 1.3: /") > $out/${tag}_ab_defer.txt
     # the N > 1 path of bench.py, two gloo ranks sharing the one GPU: a functional rehearsal, not a scaling number
     python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 \
         --dist-backend gloo --workload c4 --no-cpu-baseline 2> $out/rehearsal.err | grep '^{' > $out/${tag}_rehearsal_c4_gloo_world2.json
