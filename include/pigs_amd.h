@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PIGS_ABI_VERSION 7
+#define PIGS_ABI_VERSION 8
 
 enum pigs_status {
     PIGS_OK = 0,
@@ -234,6 +234,16 @@ size_t pigs_plan_error_offset(void);
  * through it.  `samples` must therefore stay allocated and unmodified for as long as the samples workspace is
  * used (the sorted order has no such requirement; a caller that cannot promise it sets PIGS_LATTICE=0). */
 size_t pigs_samples_lattice_offset(void);
+
+/* Byte offset, inside a PLAN workspace, of one uint32: non-zero when the build kept the Gaussians in the CALLER's
+ * order (ABI 8).  Gaussians whose order in the arrays is already spatial -- the reference lays them out on a meshgrid
+ * (model_pn.py:338-342) and training moves them by fractions of a spacing -- are not binned into grid cells: every
+ * 16 consecutive ones are a strip with a bounding box (16 strips a super-strip), and the tile lists are built from
+ * those boxes; no count, scan or scatter launch.  The library measures in every build how many times over the strips cover
+ * the samples' domain and decides the next build of the same sizes from the last completed measurement (at most 64 times: strips);
+ * always correct whatever the order, results never depend on it beyond the order of a list's entries;
+ * PIGS_GAUSS_STRIPS=0 / 1 in the environment: never / always. */
+size_t pigs_plan_strips_offset(void);
 
 /* Introspection for tools and tests (never needed to use a plan): where the tile lists sit inside a
  * plan workspace.  info[0] = tiles, info[1] = entries per list slab, info[2] = byte offset of the

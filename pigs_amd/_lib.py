@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIGS_AMD_LIB") or os.path.join(HERE, "libpigs_amd.so")
 
 PIGS_F32, PIGS_F64 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -36,6 +36,7 @@ SIGNATURES = {
     "pigs_samples_error_offset": (ctypes.c_size_t, []),
     "pigs_plan_error_offset": (ctypes.c_size_t, []),
     "pigs_samples_lattice_offset": (ctypes.c_size_t, []),
+    "pigs_plan_strips_offset": (ctypes.c_size_t, []),
     "pigs_samples_build": (_i, [_vp, ctypes.c_size_t, _i64, _vp, _vp]),
     "pigs_samples_order_hint": (_i, [_i64]),
     "pigs_plan_build": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _i64, _i64, _i, ctypes.c_float, ctypes.c_float]

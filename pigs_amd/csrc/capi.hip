@@ -89,6 +89,7 @@ size_t pigs_plan_workspace_bytes(int64_t N, int64_t M, int c) { return plan_work
 size_t pigs_samples_error_offset(void) { return samples_error_offset(); }
 size_t pigs_plan_error_offset(void) { return plan_error_offset(); }
 size_t pigs_samples_lattice_offset(void) { return samples_lattice_offset(); }
+size_t pigs_plan_strips_offset(void) { return plan_strips_offset(); }
 
 int pigs_plan_layout_info(int64_t N, int64_t M, int c, int64_t info[6]) {
     if (!info) return PIGS_ERR_INVALID;

@@ -101,6 +101,7 @@ struct TravLds {
     uint32_t row_a0[64];
     uint32_t row_a1[64];
     uint32_t cand[CCAP];
+    uint32_t strip[256];          // traverse_strips: the hit strips of 16 super-strips
 };
 
 template <typename Rows, typename Batch>
@@ -216,5 +217,105 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same for a plan that kept the Gaussians in the caller's order (PlanParams::strips): candidates come from boxes,
+// coarse to fine.  Stage 1: 256 super-strip boxes at a time (four loads per lane in flight), the hits to an LDS list.
+// Stage 2: the 16 strip boxes of 16 hit super-strips at a time (four loads in flight), the hit strips to a second
+// list.  Stage 3: the records of four hit strips per step, the next two steps' in flight under the current one's exact
+// test, handed to `batch` as above (j = the Gaussian's own index).  About as many dependent round trips as the grid's
+// starts -> boxes -> records.  walk == false: only `rows`, with the hit super-strips as record ranges (the RANGES
+// fall-back of a tile whose lists do not fit).
+// ------------------------------------------------------------------------------------------
+template <typename Rows, typename Batch>
+__device__ __forceinline__ void traverse_strips(const PlanView& pv, float bx0, float by0, float bx1, float by1, int lane,
+                                                TravLds& lds, bool walk, Rows&& rows, Batch&& batch) {
+    const uint32_t N = pv.N;
+    const uint32_t nsuper = (N + SUPER - 1u) / SUPER, nstrip = (N + STRIP - 1u) / STRIP;
+    // (a NaN in a box -- a NaN centre -- keeps it: every comparison is written to accept)
+    auto reaches = [&](const float4 b) { return !(b.x > bx1) && !(b.z < bx0) && !(b.y > by1) && !(b.w < by0); };
+    const uint32_t slot = (uint32_t)lane >> 4, sub = (uint32_t)lane & 15u;
+    static_assert(CCAP >= 256, "the hit super-strips of a chunk of 256");
+    for (uint32_t c0 = 0; c0 < nsuper; c0 += 256u) {
+        // ---- stage 1
+        float4 sb[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t sup = c0 + 64u * k + (uint32_t)lane;
+            sb[k] = pv.sbox[sup < nsuper ? sup : 0u];
+        }
+        uint32_t nhs = 0;
+        wave_lds_fence();
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t sup = c0 + 64u * k + (uint32_t)lane;
+            const bool hit = sup < nsuper && reaches(sb[k]);
+            const uint64_t hm = __ballot(hit);
+            if (hit) lds.cand[nhs + (uint32_t)lanes_below(hm)] = sup;
+            nhs += (uint32_t)__builtin_popcountll(hm);
+        }
+        wave_lds_fence();
+        if (!walk) {
+            for (uint32_t h0 = 0; h0 < nhs; h0 += 64u) {
+                const uint32_t nrow = nhs - h0 < 64u ? nhs - h0 : 64u;
+                uint32_t jb = 0, len = 0;
+                if ((uint32_t)lane < nrow) {
+                    jb = lds.cand[h0 + (uint32_t)lane] * SUPER;
+                    len = N - jb < SUPER ? N - jb : SUPER;
+                }
+                rows((int)nrow, jb, len);
+            }
+            continue;
+        }
+        for (uint32_t h0 = 0; h0 < nhs; h0 += 16u) {
+            // ---- stage 2: 16 hit super-strips = 256 strip boxes
+            float4 pb[4];
+            uint32_t sidx[4];
+            bool in[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t h = h0 + 4u * k + slot;
+                in[k] = h < nhs;
+                sidx[k] = lds.cand[in[k] ? h : h0] * SUPER_STRIPS + sub;
+                in[k] = in[k] && sidx[k] < nstrip;
+                pb[k] = pv.pbox[in[k] ? sidx[k] : 0u];
+            }
+            uint32_t np = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const bool hit = in[k] && reaches(pb[k]);
+                const uint64_t hm = __ballot(hit);
+                if (hit) lds.strip[np + (uint32_t)lanes_below(hm)] = sidx[k];
+                np += (uint32_t)__builtin_popcountll(hm);
+            }
+            if (np == 0u) continue;
+            wave_lds_fence();
+            // ---- stage 3: four strips per step, the next step's records requested before the current step is tested
+            auto fetch = [&](uint32_t k0, float4& A, float4& B, uint32_t& j, bool& ok) __attribute__((always_inline)) {
+                const bool hv = k0 + slot < np;
+                const uint32_t st = lds.strip[hv ? k0 + slot : k0];
+                j = st * STRIP + sub;
+                ok = hv && j < N;
+                if (!ok) j = 0u;
+                A = pv.rec[2 * j]; B = pv.rec[2 * j + 1];
+            };
+            float4 A0, B0, A1, B1;
+            uint32_t j0, j1 = 0u;
+            bool ok0, ok1 = false;
+            fetch(0u, A0, B0, j0, ok0);
+            A1 = A0; B1 = B0;
+            if (4u < np) fetch(4u, A1, B1, j1, ok1);
+            for (uint32_t k0 = 0; k0 < np; k0 += 4u) {       // (two steps' records in flight under the test of a third)
+                const float4 Ac = A0, Bc = B0;
+                const uint32_t jc = j0;
+                const bool okc = ok0;
+                A0 = A1; B0 = B1; j0 = j1; ok0 = ok1;
+                if (k0 + 8u < np) fetch(k0 + 8u, A1, B1, j1, ok1);
+                const uint64_t m = __ballot(okc && ellipse_reaches_rect(Ac, Bc.x, bx0, by0, bx1, by1, pv.q_max));
+                if (m) batch(Ac, Bc, m, jc);
+            }
+            wave_lds_fence();
+        }
+    }
+}
 
 }  // namespace pigs

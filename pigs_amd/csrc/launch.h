@@ -66,6 +66,7 @@ int aggregate_grid_build(void* ws, size_t ws_bytes, int64_t N, float q_grid, con
                          hipStream_t stream);
 size_t samples_error_offset();
 size_t samples_lattice_offset();
+size_t plan_strips_offset();
 size_t plan_error_offset();
 
 // Order masks: bit k < 4 = derivative order k (pointer slot k); bit 4 (16) = the TRACE of the order-2

@@ -173,7 +173,21 @@ struct PlanParams {
     float q_f, q_b;        // the plan's two cut-offs (forward / backward of order >= 2 gradients), q_b >= q_f
     uint32_t bar[PLAN_BAR_WORDS];   // device-wide barriers of the one-launch Gaussian chain (zero between builds)
     uint32_t n_points;              // tiles in TILE_MODE_POINTS (queued in `ptiles` by the list build)
+    // STRIPS (round 4; plan.hip, gauss_pack_part).  Gaussians that arrive in an order in which neighbours in the array are
+    // neighbours in space (the reference lays them out on a meshgrid, model_pn.py:338-342, and training moves them by
+    // fractions of a spacing) are not binned at all: records stay in the CALLER's order, every STRIP = 16 consecutive
+    // ones are a strip with a bounding box (`pbox`), every 16 strips a super-strip (`sbox`), and the list build tests
+    // a block of tiles against super-strip boxes, then strip boxes, then the strips' records (grid_walk.h,
+    // traverse_strips) instead of walking grid cells -- no count, no scan, no scatter.  Always correct (a strip box bounds its Gaussians'
+    // ellipses whatever their order); fast when the strips cover the samples' domain only a few times over:
+    // strip_cover = sum of strip box areas / domain area, measured by every build (either kind) and remembered by the
+    // library, which decides the next build's kind from it.
+    float strip_cover;              // (adjacent to n_points: one copy for the library's memory)
+    uint32_t strips;                // this build kept the caller's order (lists from strip boxes)
 };
+constexpr uint32_t STRIP = 16;                      // Gaussians per strip = a row of 16 lanes of the wave that packs it
+constexpr uint32_t SUPER_STRIPS = 16;               // strips per super-strip
+constexpr uint32_t SUPER = STRIP * SUPER_STRIPS;    // = the 256 Gaussians of a workgroup of the packing pass
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -257,6 +271,7 @@ struct PlanLayout {
     uint32_t scan_blocks;      // workgroups of the scan = ceil((gcells + 1) / PLAN_SCAN_BLOCK)
     uint32_t ntiles;           // ceil(M / 64)
     uint32_t list_cap;         // entries per list slab (one tile list + four group lists per tile), multiple of 16
+    size_t off_pbox, off_sbox, off_parea;
     size_t off_params, off_counts, off_agg, off_starts, off_gkey, off_rec, off_box, off_g2o, off_gacc, off_hdr,
         off_ptiles, off_tlist, off_glist, off_stage, total_bytes;
 };
@@ -310,6 +325,9 @@ inline PlanLayout make_plan_layout(int64_t N, int64_t M, int c) {
     p.off_rec = o;      o = align_up(o + 32 * ((size_t)N + 1), 256);           // + the all-zero record N
     p.off_box = o;      o = align_up(o + 16 * (size_t)N, 256);
     p.off_g2o = o;      o = align_up(o + sizeof(uint32_t) * (size_t)N, 256);
+    p.off_pbox = o;     o = align_up(o + sizeof(float4) * (((size_t)N + STRIP - 1) / STRIP), 256);     // strip boxes {min x, min y, max x, max y}
+    p.off_sbox = o;     o = align_up(o + sizeof(float4) * (((size_t)N + SUPER - 1) / SUPER), 256);     // super-strip boxes
+    p.off_parea = o;    o = align_up(o + sizeof(float) * (((size_t)N + STRIP - 1) / STRIP), 256);      // strip box areas / domain area
     p.off_gacc = o;     o = align_up(o + sizeof(float) * 8 * (size_t)N, 256);   // backward scratch [N][8]
     p.off_hdr = o;      o = align_up(o + sizeof(uint32_t) * TILE_HDR_WORDS * (size_t)p.ntiles, 256);
     p.off_ptiles = o;   o = align_up(o + sizeof(uint32_t) * (size_t)p.ntiles, 256);           // queue of the TILE_MODE_POINTS tiles
@@ -375,6 +393,8 @@ struct PlanView {
     uint32_t level_off[PLAN_MAX_LEVELS + 1];
     float q_max;                  // list build only: the WIDE cut-off max(q_f, q_b) (the sampling kernels read params->q_f / q_b)
     float* gacc;                  // backward scratch: [N][8] sorted-order gradient sums, one 32-byte row per Gaussian
+    const float4* pbox;           // [ceil(N / 16)] strip boxes (meaningful when params->strips)
+    const float4* sbox;           // [ceil(N / 256)] super-strip boxes
     // Staging for points in no order (null: not in this launch).  A tile of such points sends its outputs to three
     // arrays through the points' original indices: three scattered 4 / 8 / 16-byte stores per point, each of which
     // costs the memory a whole 32-byte sector (96 MB written for 28 MB of outputs at 1 M points: forward 54 us where

@@ -126,6 +126,12 @@ struct BuildArgs {
     int ahead;
     float hint_box[4];
     int s_scan_in_scatter;  // launch 3 of the chain above: no scan launch ran for the samples
+    // STRIPS (plan.h, PlanParams::strips): the Gaussians keep the caller's order -- gauss_pack_part instead of count,
+    // scan and scatter; `parea` is written by builds of either kind (the statistic the library decides from)
+    int strips;
+    float4* pbox;
+    float4* sbox;
+    float* parea;
 };
 
 __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words, uint32_t bid, uint32_t nb) {
@@ -419,6 +425,83 @@ __device__ __forceinline__ void samples_hist_part(const BuildArgs& a, uint32_t w
 // The Gaussians' half of the count: cell key (level by size, cell by centre) and rank of every Gaussian.  `box`: the
 // samples' bounding box the grid's domain is laid over -- of this build, or (BuildArgs::ahead) of the last one.
 struct GaussLoad { float m[2], c[3]; };
+// One Gaussian into its place (in cell order, or -- PlanParams::strips -- its own): records, the box the list build
+// tests first, the way back.
+__device__ __forceinline__ void gauss_scatter_one(const BuildArgs& a, uint32_t i, uint32_t pos) {
+    float v[2] = {0.f, 0.f};
+    for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
+    // {mux, muy, a, b}, {c, v0, v1, 0}
+    a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
+    a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 2], v[0], v[1], 0.f);
+    if (i == 0) {         // record N: all zero (v = 0 contributes nothing), what list positions behind a list's end read
+        a.rec[2 * (size_t)a.N] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.rec[2 * (size_t)a.N + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {   // bounding box of the q <= q_max ellipse: half extents sqrt(q_max Sigma_xx), sqrt(q_max Sigma_yy)
+        const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
+        const float k = a.q_max / (ca * cc - cb * cb);
+        float hx = sqrtf(k * cc), hy = sqrtf(k * ca);
+        if (!(hx < 3.0e38f)) hx = 3.0e38f;      // NaN / inf (degenerate conic): always a candidate
+        if (!(hy < 3.0e38f)) hy = 3.0e38f;
+        a.gbox[pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], hx * 1.0001f, hy * 1.0001f);
+    }
+    a.g2o[pos] = i;
+    // (the backward's scratch `gacc` is zero from the workspace's first build on -- zeroed once by the first
+    // launch of a build into a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN, re-zeroed by plan_unpermute_kernel
+    // behind every backward: no memset launch, and no 8 scattered stores per Gaussian here either)
+}
+
+// The boxes of the strips (16 consecutive Gaussians of the caller's array = a row of this wave's lanes) and of the
+// super-strip (the workgroup's 256): the union of the boxes of their q <= q_max ellipses.  A strip box's area over the
+// domain's goes to `parea` (summed by the list launch into PlanParams::strip_cover); the boxes themselves to `pbox` /
+// `sbox` when the build keeps the caller's order (`store`; block-uniform -- a barrier inside).  Non-finite extents (a
+// degenerate conic) and NaN centres make a strip reach everywhere.
+__device__ __forceinline__ void strip_box(const BuildArgs& a, uint32_t i, bool valid, float mx, float my, float hx, float hy,
+                                          const float* box, bool store) {
+    __shared__ float4 rowbox[16];
+    const float INF = __builtin_huge_valf();
+    if (!(hx < 3.0e38f)) hx = INF;      // NaN too
+    if (!(hy < 3.0e38f)) hy = INF;
+    float x0 = valid ? mx - hx : INF, x1 = valid ? mx + hx : -INF;
+    float y0 = valid ? my - hy : INF, y1 = valid ? my + hy : -INF;
+    if (valid && !(mx == mx)) { x0 = -INF; x1 = INF; }      // a NaN centre: fminf / fmaxf would drop it
+    if (valid && !(my == my)) { y0 = -INF; y1 = INF; }
+    row_box_dpp(x0, x1, y0, y1);
+    const bool first = (threadIdx.x & 15u) == 0u;
+    if (first && i < a.N) {
+        const uint32_t strip = i / STRIP;
+        if (store) a.pbox[strip] = make_float4(x0, y0, x1, y1);
+        // inside the domain only: what lies outside meets no tile
+        const float dx = box[2] - box[0], dy = box[3] - box[1];
+        const float w = fminf(x1, box[2]) - fmaxf(x0, box[0]), h = fminf(y1, box[3]) - fmaxf(y0, box[1]);
+        float cover = (w > 0.f && h > 0.f && dx > 0.f && dy > 0.f) ? (w * h) / (dx * dy) : 0.f;
+        if (!(cover == cover)) cover = 1.f;
+        a.parea[strip] = cover;
+    }
+    if (!store) return;
+    if (first) rowbox[threadIdx.x >> 4] = make_float4(x0, y0, x1, y1);
+    __syncthreads();
+    if (threadIdx.x == 0 && i < a.N) {
+        float4 b = rowbox[0];
+        for (int r = 1; r < 16; ++r) {
+            const float4 q = rowbox[r];
+            b.x = fminf(b.x, q.x); b.y = fminf(b.y, q.y); b.z = fmaxf(b.z, q.z); b.w = fmaxf(b.w, q.w);
+        }
+        a.sbox[i / SUPER] = b;
+    }
+}
+// A build that keeps the caller's order (PlanParams::strips): records, boxes and the way back at position i itself, the
+// strip's box beside them -- the whole Gaussian half of a build in one pass, no atomics.
+__device__ __forceinline__ void gauss_pack_part(const BuildArgs& a, uint32_t i, const float* box, const GaussLoad& ld) {
+    const bool valid = i < a.N;
+    float hx = 0.f, hy = 0.f;
+    if (valid) {
+        gauss_scatter_one(a, i, i);
+        const float k = a.q_max / (ld.c[0] * ld.c[2] - ld.c[1] * ld.c[1]);
+        hx = sqrtf(k * ld.c[2]) * 1.0001f; hy = sqrtf(k * ld.c[0]) * 1.0001f;      // (as gbox holds them)
+    }
+    strip_box(a, i, valid, ld.m[0], ld.m[1], hx, hy, box, true);
+}
 __device__ __forceinline__ GaussLoad gauss_count_load(const BuildArgs& a, uint32_t bid) {      // (issued early: flies while the box is reduced)
     GaussLoad ld = {{0.f, 0.f}, {0.f, 0.f, 0.f}};
     const uint32_t i = bid * 256 + threadIdx.x;
@@ -441,11 +524,25 @@ __device__ __forceinline__ void gauss_count_part(const BuildArgs& a, uint32_t bi
         a.params->q_f = a.q_f;
         a.params->q_b = a.q_b;
         a.params->n_points = 0u;
+        a.params->strips = a.strips ? 1u : 0u;
+        if (a.strips) a.params->level_mask = 0u;
 #pragma unroll
         for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
     }
+    if (a.strips) {                    // launch-uniform: the caller's order is kept (PlanParams::strips)
+        gauss_pack_part(a, i, box, ld);
+        return;
+    }
     uint32_t key = 0xffffffffu;
     int l = 0;
+    {   // the statistic the library decides the NEXT build's kind from: this wave's Gaussians as four strips
+        float hx = 0.f, hy = 0.f;
+        if (valid) {
+            const float k = a.q_max / (gc[0] * gc[2] - gc[1] * gc[1]);
+            hx = sqrtf(k * gc[2]); hy = sqrtf(k * gc[0]);
+        }
+        strip_box(a, i, valid, gm[0], gm[1], hx, hy, box, false);
+    }
     if (valid) {
         const float mx = gm[0], my = gm[1];
         const float ca = gc[0], cb = gc[1], cc = gc[2];
@@ -481,7 +578,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     const int lane = threadIdx.x & 63;
     // BuildArgs::ahead: the Gaussians were counted in the first launch -- the first workgroups of THIS one scan their
     // cells (look-back among the launch's first workgroups, as in plan_scan_kernel), the samples' workgroups follow
-    const uint32_t shift = a.ahead ? a.scan_blocks : 0u;
+    const uint32_t shift = a.ahead && !a.strips ? a.scan_blocks : 0u;
     if (blockIdx.x < shift) {                            // block-uniform
         scan_block<false>(a, true, blockIdx.x, scan_sh, scan_sh2);
         return;
@@ -711,7 +808,7 @@ __device__ __forceinline__ void scan_block(const BuildArgs& a, bool seg0, uint32
 __global__ __launch_bounds__(256) void plan_scan_kernel(BuildArgs a) {
     __shared__ uint32_t sh[4];
     __shared__ uint32_t sh2[4];
-    const uint32_t nb0 = a.do_plan ? a.scan_blocks : 0;
+    const uint32_t nb0 = a.do_plan && !a.strips ? a.scan_blocks : 0;
     const bool seg0 = blockIdx.x < nb0;
     if (!seg0 && a.sparams->lat[0] != 0u) return;      // index-tiled points: nothing was counted (block-uniform)
     scan_block<false>(a, seg0, seg0 ? blockIdx.x : blockIdx.x - nb0, sh, sh2);
@@ -822,10 +919,10 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     extern __shared__ uint4 scatter_stage[];      // coarse-bin path with a chunk that fits: [h_chunk] records + 2 x 256 words
     __shared__ uint32_t scan_lds[PLAN_SCAN_BLOCK];
     __shared__ uint32_t scan_ws[4];
-    const uint32_t gblocks = a.do_plan ? (a.N + 255) / 256 : 0;
+    const uint32_t gblocks = a.do_plan && !a.strips ? (a.N + 255) / 256 : 0;      // (strips: the Gaussians are in place already)
     const bool gpart = blockIdx.x < gblocks;
     const uint32_t i = (gpart ? blockIdx.x : blockIdx.x - gblocks) * 256 + threadIdx.x;
-    if (a.do_plan && blockIdx.x == 0 && threadIdx.x < 64) {
+    if (a.do_plan && !a.strips && blockIdx.x == 0 && threadIdx.x < 64) {
         // level l holds a Gaussian iff its cells' scanned range is not empty (no atomics, no scratch)
         const int l = (int)threadIdx.x;
         const int lc = l < a.L ? l : 0;
@@ -833,7 +930,7 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
         const uint64_t m = __ballot(occ);
         if (threadIdx.x == 0) a.params->level_mask = (uint32_t)m;
     }
-    if (a.do_plan) {
+    if (a.do_plan && !a.strips) {
         // the scan has consumed the counters and its own flags: leave them zeroed, so that a later
         // build into this workspace (PIGS_BUILD_PLAN_WS_CLEAN) needs no zeroing launch
         for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.zero_words; k += gridDim.x * 256) a.counts[k] = 0u;
@@ -847,28 +944,7 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(BuildArgs a) {
     }
     if (gpart && i < a.N) {
         const uint2 kr = a.gkey[i];
-        const uint32_t pos = a.starts[kr.x] + kr.y;
-        float v[2] = {0.f, 0.f};
-        for (int k = 0; k < a.c; ++k) v[k] = a.values[(size_t)i * a.c + k];
-        // {mux, muy, a, b}, {c, v0, v1, 0}
-        a.rec[2 * pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], a.conics[3 * i], a.conics[3 * i + 1]);
-        a.rec[2 * pos + 1] = make_float4(a.conics[3 * i + 2], v[0], v[1], 0.f);
-        if (i == 0) {         // record N: all zero (v = 0 contributes nothing), what list positions behind a list's end read
-            a.rec[2 * (size_t)a.N] = make_float4(0.f, 0.f, 0.f, 0.f);
-            a.rec[2 * (size_t)a.N + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        {   // bounding box of the q <= q_max ellipse: half extents sqrt(q_max Sigma_xx), sqrt(q_max Sigma_yy)
-            const float ca = a.conics[3 * i], cb = a.conics[3 * i + 1], cc = a.conics[3 * i + 2];
-            const float k = a.q_max / (ca * cc - cb * cb);
-            float hx = sqrtf(k * cc), hy = sqrtf(k * ca);
-            if (!(hx < 3.0e38f)) hx = 3.0e38f;      // NaN / inf (degenerate conic): always a candidate
-            if (!(hy < 3.0e38f)) hy = 3.0e38f;
-            a.gbox[pos] = make_float4(a.means[2 * i], a.means[2 * i + 1], hx * 1.0001f, hy * 1.0001f);
-        }
-        a.g2o[pos] = i;
-        // (the backward's scratch `gacc` is zero from the workspace's first build on -- zeroed once by the first
-        // launch of a build into a workspace that is not PIGS_BUILD_PLAN_WS_CLEAN, re-zeroed by plan_unpermute_kernel
-        // behind every backward: no memset launch, and no 8 scattered stores per Gaussian here either)
+        gauss_scatter_one(a, i, a.starts[kr.x] + kr.y);
     }
     uint32_t sstart = 0;
     if (!gpart && a.s_scan_in_scatter) {      // block-uniform: an expected lattice that was none, and no scan launch ran
@@ -1090,6 +1166,7 @@ __global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
         a.params->q_f = a.q_f;
         a.params->q_b = a.q_b;
         a.params->n_points = 0u;
+        a.params->strips = 0u;
 #pragma unroll
         for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
     }
@@ -1210,18 +1287,21 @@ struct ListArgs {
     uint32_t* ptiles;     // queue of the tiles in TILE_MODE_POINTS
     uint32_t* n_points;   //   and its length (PlanParams::n_points, zeroed by the count kernel)
     float q_f;            // the narrow cut-off (pv.q_max is the wide one)
+    const float* parea;   // per strip: box area / domain area (written by the build's Gaussian pass)
+    float* strip_cover;   //   their sum (PlanParams::strip_cover)
 };
 
 // the lists of the TPW tiles from tile0 (one wave).  TPW = 4 (a 4 x 4 block of sample cells: the traversal of the grid is
 // shared by four tiles) where the launch fills the chip; TPW = 1 for small point sets (LISTS_SMALL_TILES): the launch's
 // time is the serial life of ONE wave there (21 us at 65 536 points with four tiles per wave, the chip nearly idle), and
 // a wave with a quarter of the work has a shorter life.
-template <int TPW>
+template <int TPW, bool STRIPS = false>
 __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TPW>& lds, uint32_t tile0, int lane) {
     const PlanView& pv = a.pv;
     const uint32_t ntiles = a.sv.ntiles;
     const GaussGrid gg = pv.params->gg;
     const uint32_t level_mask = pv.params->level_mask;
+    constexpr bool strips = STRIPS;                       // candidates from strip boxes, not from grid cells (PlanParams::strips)
     const uint32_t loff = pv.params->level_off[lane < PLAN_MAX_LEVELS ? lane : 0];   // lane = level: its first counter
     const float INF = __builtin_huge_valf();
     SPoint sp[TPW];
@@ -1261,7 +1341,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
     // A block of 256 points spread over more than POINTS_MODE_BLOCK_CELLS finest Gaussian cells (a group of 16 then
     // spans dozens of cells: its list would run to hundreds) goes to the per-point walk without being listed at
     // all: the traversal of such a box is the list build's own tail (thousands of candidates in one wave).
-    if ((bx1 - bx0) * gg.inv_s0 * ((by1 - by0) * gg.inv_s0) > POINTS_MODE_BLOCK_CELLS && walk_candidates() <= 4.f * (float)cap) {
+    if (!strips && (bx1 - bx0) * gg.inv_s0 * ((by1 - by0) * gg.inv_s0) > POINTS_MODE_BLOCK_CELLS && walk_candidates() <= 4.f * (float)cap) {
         for (int t = 0; t < TPW; ++t) {
             if (tile0 + (uint32_t)t >= ntiles) break;
             if (lane < TILE_HDR_WORDS)
@@ -1384,7 +1464,11 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
 #endif
         sn = 0;
     };
-    traverse(pv, gg, level_mask, loff, bx0, by0, bx1, by1, lane, lds.trav, true,
+    auto walk_rect = [&](float x0, float y0, float x1, float y1, bool walk, auto&& rows, auto&& batch) __attribute__((always_inline)) {
+        if constexpr (STRIPS) traverse_strips(pv, x0, y0, x1, y1, lane, lds.trav, walk, rows, batch);
+        else traverse(pv, gg, level_mask, loff, x0, y0, x1, y1, lane, lds.trav, walk, rows, batch);
+    };
+    walk_rect(bx0, by0, bx1, by1, true,
              [](int, uint32_t, uint32_t) {},
              [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) __attribute__((always_inline)) {
         if (mask >> lane & 1ull) {
@@ -1433,7 +1517,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
         uint32_t longest = ng[t][0] > ng[t][1] ? ng[t][0] : ng[t][1];
         longest = ng[t][2] > longest ? ng[t][2] : longest;
         longest = ng[t][3] > longest ? ng[t][3] : longest;
-        if (longest > POINTS_MODE_MIN_LIST) {
+        if (longest > POINTS_MODE_MIN_LIST && !strips) {      // (the per-point walk needs the grid)
             float4 gb[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) gb[g] = lds.gbox[t * 4 + g];
@@ -1491,7 +1575,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
             uint32_t* gl = a.glist + (size_t)(tile0 + (uint32_t)t) * 4 * cap;
             uint32_t ngw[4] = {0u, 0u, 0u, 0u};
             bool gover = false;
-            traverse(pv, gg, level_mask, loff, tx0, ty0, tx1, ty1, lane, lds.trav, true,
+            walk_rect(tx0, ty0, tx1, ty1, true,
                      [](int, uint32_t, uint32_t) {},
                      [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) __attribute__((always_inline)) {
                 const bool have = mask >> lane & 1ull;
@@ -1525,7 +1609,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
         }
         // scattered points (a box of many Gaussian cells for 64 points): no lists, every lane walks the grid
         // around its own point at sampling time (plan.h, TILE_MODE_POINTS)
-        if ((tx1 - tx0) * gg.inv_s0 * ((ty1 - ty0) * gg.inv_s0) > POINTS_MODE_MIN_CELLS && walk_candidates() <= 4.f * (float)cap) {
+        if (!strips && (tx1 - tx0) * gg.inv_s0 * ((ty1 - ty0) * gg.inv_s0) > POINTS_MODE_MIN_CELLS && walk_candidates() <= 4.f * (float)cap) {
             if (lane < 5)
                 a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (TILE_MODE_POINTS << TILE_MODE_SHIFT) : 0u;
             if (lane == 0) a.ptiles[atomicAdd(a.n_points, 1u)] = tile0 + (uint32_t)t;
@@ -1533,7 +1617,7 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
         }
         uint32_t nr = 0;
         bool fits = true;
-        traverse(pv, gg, level_mask, loff, tx0, ty0, tx1, ty1, lane, lds.trav, false,
+        walk_rect(tx0, ty0, tx1, ty1, false,
                  [&](int nrow, uint32_t jb, uint32_t len) {
             const bool keep = lane < nrow && len > 0;
             const uint64_t km = __ballot(keep);
@@ -1562,14 +1646,30 @@ template <int TPW>
 __device__ __forceinline__ uint32_t lists_tile0(int wave) {
     return (xcd_block_chunk<PIGS_XCD_CHUNK / TPW>(gridDim.x) * 4 + (uint32_t)wave) * TPW;
 }
-template <int TPW>
+// the first workgroup of a list launch: the strips' cover of the domain (PlanParams::strip_cover), summed from what the
+// build's Gaussian pass left per strip
+__device__ __forceinline__ void lists_strip_cover(const ListArgs& a) {
+    __shared__ float cover_sh[4];
+    if (blockIdx.x != 0) return;
+    const uint32_t ns = (a.pv.N + STRIP - 1u) / STRIP;
+    float sum = 0.f;
+    for (uint32_t k = threadIdx.x; k < ns; k += 256u) sum += a.parea[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63u) == 0u) cover_sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.strip_cover[0] = cover_sh[0] + cover_sh[1] + cover_sh[2] + cover_sh[3];
+}
+
+template <int TPW, bool STRIPS>
 __global__ __launch_bounds__(256) void plan_lists_kernel(ListArgs a) {
     __shared__ ListsLds<TPW> lds_all[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    lists_strip_cover(a);
     const uint32_t tile0 = lists_tile0<TPW>(wave);
     if (tile0 >= a.sv.ntiles) return;
-    build_block_lists<TPW>(a, lds_all[wave], tile0, lane);
+    build_block_lists<TPW, STRIPS>(a, lds_all[wave], tile0, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2047,6 +2147,7 @@ __global__ __launch_bounds__(256) void plan_lists_forward_kernel(ListArgs a, flo
     static_assert(sizeof(FwdLds) <= sizeof(ListsLds<LISTS_TPW>), "the forward's queues live in the list build's LDS");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    lists_strip_cover(a);
     const uint32_t tile0 = lists_tile0<LISTS_TPW>(wave);
     const uint32_t ntiles = a.sv.ntiles;
     if (tile0 >= ntiles) return;
@@ -2692,6 +2793,8 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
     for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) v.level_off[l] = p.level_off[l];
     v.q_max = q_max;
     v.gacc = (float*)(b + p.off_gacc);
+    v.pbox = (const float4*)(b + p.off_pbox);
+    v.sbox = (const float4*)(b + p.off_sbox);
     v.stage = (float4*)(b + p.off_stage);
     return v;
 }
@@ -2699,6 +2802,7 @@ static PlanView make_view(const PlanLayout& p, void* ws, float q_max) {
 size_t samples_error_offset() { return offsetof(SampleParams, scan_error); }
 size_t plan_error_offset() { return offsetof(PlanParams, scan_error); }
 size_t samples_lattice_offset() { return offsetof(SampleParams, lat); }
+size_t plan_strips_offset() { return offsetof(PlanParams, strips); }      // (the parameters open the workspace)
 
 int plan_layout_info(int64_t N, int64_t M, int c, int64_t* info) {
     if (!plan_supported(N, M, c)) return PIGS_ERR_UNSUPPORTED;
@@ -2939,6 +3043,9 @@ static void fill_plan_args(BuildArgs& a, const PlanLayout& p, void* ws, float q_
     a.gbox = (float4*)(b + p.off_box);
     a.gacc = (float*)(b + p.off_gacc);
     a.g2o = (uint32_t*)(b + p.off_g2o);
+    a.pbox = (float4*)(b + p.off_pbox);
+    a.sbox = (float4*)(b + p.off_sbox);
+    a.parea = (float*)(b + p.off_parea);
     a.means = (const float*)means; a.conics = (const float*)conics; a.values = (const float*)values;
     a.N = (uint32_t)p.N; a.c = p.c; a.G0 = p.G0; a.L = p.L;
     a.scan_blocks = p.scan_blocks;
@@ -2980,11 +3087,15 @@ struct PointsHint {
     int device = -1;
     int64_t N = 0, M = 0;
     bool has_points = false, pending = false;
+    float cover = -1.f;            // PlanParams::strip_cover of the last completed build (< 0: none yet)
+    bool strips = false;           // ... and whether that build kept the caller's order
     uint32_t builds = 0;
     hipEvent_t ev = nullptr;
-    uint32_t* host = nullptr;
+    uint32_t* host = nullptr;      // pinned {n_points, strip_cover, strips}
     uint64_t stamp = 0;
 };
+static_assert(offsetof(PlanParams, strip_cover) == offsetof(PlanParams, n_points) + 4 && offsetof(PlanParams, strips) == offsetof(PlanParams, n_points) + 8,
+              "one copy: n_points, strip_cover, strips");
 static PointsHint g_phints[16];
 static void phint_poll(PointsHint& h) {          // g_hint_mu held
     if (!h.pending) return;
@@ -2993,6 +3104,9 @@ static void phint_poll(PointsHint& h) {          // g_hint_mu held
     if (q == hipSuccess) {
         h.pending = false;
         h.has_points = h.host[0] != 0u;
+        memcpy(&h.cover, &h.host[1], sizeof(float));
+        if (!(h.cover >= 0.f)) h.cover = 3.0e38f;      // NaN: as bad as it gets
+        h.strips = h.host[2] != 0u;
     }
 }
 static PointsHint* phint_entry(int device, int64_t N, int64_t M, bool create) {      // g_hint_mu held
@@ -3011,8 +3125,9 @@ static PointsHint* phint_entry(int device, int64_t N, int64_t M, bool create) { 
     }
     if (lru->ev && lru->device != device) { (void)hipEventDestroy(lru->ev); lru->ev = nullptr; }
     if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
-    if (!lru->host && hipHostMalloc((void**)&lru->host, sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (!lru->host && hipHostMalloc((void**)&lru->host, 3 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
     lru->device = device; lru->N = N; lru->M = M; lru->has_points = false; lru->pending = false; lru->builds = 0; lru->stamp = ++g_hint_clock;
+    lru->cover = -1.f; lru->strips = false;
     return lru;
 }
 static bool plan_expects_points(int64_t N, int64_t M, hipStream_t stream) {
@@ -3025,6 +3140,29 @@ static bool plan_expects_points(int64_t N, int64_t M, hipStream_t stream) {
     if (!cap) phint_poll(*h);
     return h->has_points;
 }
+// Does the next build of these sizes keep the caller's order (PlanParams::strips)?  Yes when the last completed build's
+// strips covered the samples' domain at most STRIP_MAX_COVER times -- that number is about how many strips a block of
+// tiles meets (a lattice in row order, a strip of 1 x 16 widened by its ellipses' reach on every side: ~10 times at
+// kappa = 0.5, ~17 at 0.8, ~33 at 1.3; Gaussians in no order: every strip covers the domain, N / 16 times).
+// PIGS_GAUSS_STRIPS=0 / 1: never / always.
+constexpr float STRIP_MAX_COVER = 64.f;
+constexpr int64_t STRIP_MIN_GAUSSIANS = 1024;      // (below, the chain it replaces is not what a step waits for)
+static bool plan_takes_strips(int64_t N, int64_t M, bool with_samples, hipStream_t stream) {
+    if (const char* e = getenv("PIGS_GAUSS_STRIPS")) return e[0] == '1';
+    // a build that sorts or looks at the samples too has its launches anyway -- the Gaussians' count, scan and scatter ride
+    // along in them -- and the lists from strips take ~3.5 us longer at C3 than the lists from cells (25.3 against 21.7 us):
+    // only builds on a finished samples workspace keep the caller's order (C3 65.5 -> 59.9 us, kappa 1.3 197 -> 186,
+    // BASELINE configs[1]'s sizes 32.0 -> 21.9: sums of kernel averages, same box)
+    if (with_samples || N < STRIP_MIN_GAUSSIANS) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const bool cap = stream_capturing(stream);
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    PointsHint* h = phint_entry(dev, N, M, false);
+    if (!h) return false;
+    if (!cap) phint_poll(*h);
+    return h->cover >= 0.f && h->cover <= STRIP_MAX_COVER;
+}
 static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t stream) {      // behind a list build
     if (stream_capturing(stream)) return;
     int dev = 0;
@@ -3033,9 +3171,11 @@ static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t st
     PointsHint* h = phint_entry(dev, p.N, p.M, true);
     if (!h) return;
     const uint32_t nth = h->builds++;
-    if (h->pending || (nth >= 2u && (nth & 15u) != 0u)) return;
+    // (builds that keep the caller's order run on an expectation -- strips that cover the domain a few times over -- and
+    // Gaussians that stopped meeting it should not be met 15 more times)
+    if (h->pending || (nth >= 2u && (nth & (h->strips ? 3u : 15u)) != 0u)) return;
     const PlanParams* pp = (const PlanParams*)((const char*)ws + p.off_params);
-    if (hipMemcpyAsync(h->host, &pp->n_points, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+    if (hipMemcpyAsync(h->host, &pp->n_points, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
         h->pending = true;
     (void)hipGetLastError();
@@ -3053,16 +3193,20 @@ static ListArgs make_list_args(const PlanLayout& p, const SamplesLayout& s, void
     la.glist = (uint32_t*)((char*)ws + p.off_glist);
     la.ptiles = (uint32_t*)((char*)ws + p.off_ptiles);
     la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
+    la.parea = (const float*)((char*)ws + p.off_parea);
+    la.strip_cover = &((PlanParams*)((char*)ws + p.off_params))->strip_cover;
     return la;
 }
 // Small point sets (a list launch of fewer tiles than this is one sparse generation of waves): one tile per wave.
 // PIGS_BWD_BLOCK builds keep four (the block lists are per four tiles).
 constexpr uint32_t LISTS_SMALL_TILES = 4096;
-static void launch_lists(uint32_t ntiles, const ListArgs& la, hipStream_t stream) {
-    if (ntiles <= LISTS_SMALL_TILES && !PIGS_BWD_BLOCK && LISTS_TPW != 1)
-        hipLaunchKernelGGL(plan_lists_kernel<1>, dim3((ntiles + 3) / 4), dim3(256), 0, stream, la);
-    else
-        hipLaunchKernelGGL(plan_lists_kernel<LISTS_TPW>, dim3((ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW)), dim3(256), 0, stream, la);
+static void launch_lists(uint32_t ntiles, const ListArgs& la, hipStream_t stream, bool strips = false) {
+    const bool small = ntiles <= LISTS_SMALL_TILES && !PIGS_BWD_BLOCK && LISTS_TPW != 1;
+    const dim3 grid(small ? (ntiles + 3) / 4 : (ntiles + 4 * LISTS_TPW - 1) / (4 * LISTS_TPW));
+    if (small && strips) hipLaunchKernelGGL((plan_lists_kernel<1, true>), grid, dim3(256), 0, stream, la);
+    else if (small) hipLaunchKernelGGL((plan_lists_kernel<1, false>), grid, dim3(256), 0, stream, la);
+    else if (strips) hipLaunchKernelGGL((plan_lists_kernel<LISTS_TPW, true>), grid, dim3(256), 0, stream, la);
+    else hipLaunchKernelGGL((plan_lists_kernel<LISTS_TPW, false>), grid, dim3(256), 0, stream, la);
 }
 
 // The chain bbox -> count -> scan -> scatter for the samples (build_samples), the Gaussians
@@ -3103,11 +3247,16 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     const bool ahead = do_samples && do_plan && plan_ws_clean && !coarse && !no_lookback && !PIGS_FUSED_BUILD && !no_ahead &&
                        a.rf_hint != 0u && !a.no_lattice && box_ok && s.scan_blocks <= 1024u;
     a.ahead = ahead; a.s_scan_in_scatter = ahead;
+    // Gaussians whose order in the caller's array is already spatial keep it (PlanParams::strips): one pass instead of
+    // count, scan and scatter
+    const bool strips = do_plan && build_lists && !defer_lists && !no_lookback && !PIGS_FUSED_BUILD && !PIGS_BWD_BLOCK &&
+                        plan_takes_strips(N, M, do_samples, stream);
+    a.strips = strips;
     if (ahead) {
         a.s_blocks = (uint32_t)((M + 1023) / 1024);
         hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks + gb), dim3(BBOX_THREADS), 0, stream, a);
-        hipLaunchKernelGGL(plan_count_kernel, dim3(p.scan_blocks + (a.s_blocks + 7u) / 8u), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (uint32_t)((M + 255) / 256)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_count_kernel, dim3((strips ? 0u : p.scan_blocks) + (a.s_blocks + 7u) / 8u), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_scatter_kernel, dim3((strips ? 0u : gb) + (uint32_t)((M + 255) / 256)), dim3(256), 0, stream, a);
     } else
     if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks), dim3(BBOX_THREADS), 0, stream, a);
     else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);
@@ -3122,12 +3271,13 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
         a.s_blocks = (uint32_t)((M + 1023) / 1024);
         const uint32_t count_wgs = coarse ? s.h_wgs : (a.rf_hint && !a.no_lattice ? (a.s_blocks + 7u) / 8u : a.s_blocks);
         hipLaunchKernelGGL(plan_count_kernel, dim3(gb + (do_samples ? count_wgs : 0u)), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(plan_scan_kernel, dim3((do_plan ? p.scan_blocks : 0u) + (do_samples ? a.s_scan_blocks : 0u)),
-                           dim3(256), 0, stream, a);
+        const uint32_t scan_wgs = (do_plan && !strips ? p.scan_blocks : 0u) + (do_samples ? a.s_scan_blocks : 0u);
+        if (scan_wgs) hipLaunchKernelGGL(plan_scan_kernel, dim3(scan_wgs), dim3(256), 0, stream, a);
         const bool staged = coarse && s.h_chunk <= SCATTER_STAGE_MAX;
-        const uint32_t scatter_wgs = staged ? s.h_wgs : (uint32_t)((M + 255) / 256);
-        hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (do_samples ? scatter_wgs : 0u)), dim3(256),
-                           staged ? s.h_chunk * sizeof(uint4) + 2 * SAMPLES_COARSE_BINS * sizeof(uint32_t) : 0, stream, a);
+        const uint32_t scatter_wgs = (strips ? 0u : gb) + (do_samples ? (staged ? s.h_wgs : (uint32_t)((M + 255) / 256)) : 0u);
+        if (scatter_wgs)
+            hipLaunchKernelGGL(plan_scatter_kernel, dim3(scatter_wgs), dim3(256),
+                               staged ? s.h_chunk * sizeof(uint4) + 2 * SAMPLES_COARSE_BINS * sizeof(uint32_t) : 0, stream, a);
         if (coarse) {
             if (s.cells_per_bin * 16u <= SAMPLES_MAX_CELLS_PER_BIN)      // the LDS holds 16 sub-cell counters per cell
                 hipLaunchKernelGGL(samples_binsort_kernel<16>, dim3(SAMPLES_COARSE_BINS), dim3(1024),
@@ -3138,7 +3288,7 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
         }
     }
     if (do_plan && build_lists && !defer_lists)
-        launch_lists(s.ntiles, make_list_args(p, s, ws, sws, q_max, a.q_max), stream);
+        launch_lists(s.ntiles, make_list_args(p, s, ws, sws, q_max, a.q_max), stream, strips);
     const int rc = launch_status();
     if (do_plan) defer_set(ws, build_lists && defer_lists && rc == PIGS_OK, q_max, a.q_max);
     if (do_plan && build_lists && !defer_lists && rc == PIGS_OK) plan_note_points(p, ws, stream);
