@@ -223,8 +223,8 @@ __device__ __forceinline__ void traverse(const PlanView& pv, const GaussGrid& gg
 // Stage 2: the 16 strip boxes of 16 hit super-strips at a time (four loads in flight), the hit strips to a second
 // list.  Stage 3: the records of four hit strips per step, the next two steps' in flight under the current one's exact
 // test, handed to `batch` as above (j = the Gaussian's own index).  About as many dependent round trips as the grid's
-// starts -> boxes -> records.  walk == false: only `rows`, with the hit super-strips as record ranges (the RANGES
-// fall-back of a tile whose lists do not fit).
+// starts -> boxes -> records.  walk == false: stages 1 and 2, then `rows` with the hit strips as record ranges, runs of
+// consecutive strips merged (the RANGES fall-back of a tile whose lists do not fit).
 // ------------------------------------------------------------------------------------------
 template <typename Rows, typename Batch>
 __device__ __forceinline__ void traverse_strips(const PlanView& pv, float bx0, float by0, float bx1, float by1, int lane,
@@ -254,18 +254,6 @@ __device__ __forceinline__ void traverse_strips(const PlanView& pv, float bx0, f
             nhs += (uint32_t)__builtin_popcountll(hm);
         }
         wave_lds_fence();
-        if (!walk) {
-            for (uint32_t h0 = 0; h0 < nhs; h0 += 64u) {
-                const uint32_t nrow = nhs - h0 < 64u ? nhs - h0 : 64u;
-                uint32_t jb = 0, len = 0;
-                if ((uint32_t)lane < nrow) {
-                    jb = lds.cand[h0 + (uint32_t)lane] * SUPER;
-                    len = N - jb < SUPER ? N - jb : SUPER;
-                }
-                rows((int)nrow, jb, len);
-            }
-            continue;
-        }
         for (uint32_t h0 = 0; h0 < nhs; h0 += 16u) {
             // ---- stage 2: 16 hit super-strips = 256 strip boxes
             float4 pb[4];
@@ -289,6 +277,38 @@ __device__ __forceinline__ void traverse_strips(const PlanView& pv, float bx0, f
             }
             if (np == 0u) continue;
             wave_lds_fence();
+            if (!walk) {
+                // the hit strips (ascending) as record ranges, runs of consecutive strips merged: a lattice in row order
+                // gives one range per row of the lattice that the rectangle's reach crosses
+                for (uint32_t k0 = 0; k0 < np; k0 += 64u) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const bool have = k < np;
+                    const uint32_t st = lds.strip[have ? k : k0];
+                    const uint32_t prev = lds.strip[have && lane > 0 ? k - 1u : k0];
+                    const bool start = have && (lane == 0 || st != prev + 1u);
+                    const uint64_t sm = __ballot(start);
+                    const uint64_t hv = __ballot(have);
+                    // this start's run ends in front of the next start (or of the chunk's last strip in hand)
+                    const uint64_t above = lane < 63 ? sm >> (lane + 1) : 0ull;
+                    const uint32_t nh = (uint32_t)__builtin_popcountll(hv);
+                    const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : nh - (uint32_t)lane;
+                    const uint32_t nrow = (uint32_t)__builtin_popcountll(sm);
+                    wave_lds_fence();
+                    if (start) {
+                        const uint32_t r = (uint32_t)lanes_below(sm);
+                        const uint32_t jb = st * STRIP;
+                        const uint32_t len = run * STRIP;
+                        lds.row_a0[r] = jb;
+                        lds.row_a1[r] = N - jb < len ? N - jb : len;
+                    }
+                    wave_lds_fence();
+                    uint32_t jb = 0, len = 0;
+                    if ((uint32_t)lane < nrow) { jb = lds.row_a0[lane]; len = lds.row_a1[lane]; }
+                    wave_lds_fence();
+                    rows((int)nrow, jb, len);
+                }
+                continue;
+            }
             // ---- stage 3: four strips per step, the next step's records requested before the current step is tested
             auto fetch = [&](uint32_t k0, float4& A, float4& B, uint32_t& j, bool& ok) __attribute__((always_inline)) {
                 const bool hv = k0 + slot < np;

@@ -184,6 +184,9 @@ struct PlanParams {
     // library, which decides the next build's kind from it.
     float strip_cover;              // (adjacent to n_points: one copy for the library's memory)
     uint32_t strips;                // this build kept the caller's order (lists from strip boxes)
+    uint32_t points_wanted;         // ... and met this many blocks / tiles of far-apart points, which a build through the
+                                    // cells would have left to the per-point walk (TILE_MODE_POINTS needs the grid): the
+                                    // library then goes back to the cells
 };
 constexpr uint32_t STRIP = 16;                      // Gaussians per strip = a row of 16 lanes of the wave that packs it
 constexpr uint32_t SUPER_STRIPS = 16;               // strips per super-strip

@@ -525,6 +525,7 @@ __device__ __forceinline__ void gauss_count_part(const BuildArgs& a, uint32_t bi
         a.params->q_b = a.q_b;
         a.params->n_points = 0u;
         a.params->strips = a.strips ? 1u : 0u;
+        a.params->points_wanted = 0u;
         if (a.strips) a.params->level_mask = 0u;
 #pragma unroll
         for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
@@ -1167,6 +1168,7 @@ __global__ __launch_bounds__(256) void plan_gauss_build_kernel(BuildArgs a) {
         a.params->q_b = a.q_b;
         a.params->n_points = 0u;
         a.params->strips = 0u;
+        a.params->points_wanted = 0u;
 #pragma unroll
         for (int l = 0; l <= PLAN_MAX_LEVELS; ++l) a.params->level_off[l] = a.level_off[l];
     }
@@ -1286,6 +1288,7 @@ struct ListArgs {
     uint32_t* glist;
     uint32_t* ptiles;     // queue of the tiles in TILE_MODE_POINTS
     uint32_t* n_points;   //   and its length (PlanParams::n_points, zeroed by the count kernel)
+    uint32_t* points_wanted;   // PlanParams::points_wanted
     float q_f;            // the narrow cut-off (pv.q_max is the wide one)
     const float* parea;   // per strip: box area / domain area (written by the build's Gaussian pass)
     float* strip_cover;   //   their sum (PlanParams::strip_cover)
@@ -1341,6 +1344,10 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
     // A block of 256 points spread over more than POINTS_MODE_BLOCK_CELLS finest Gaussian cells (a group of 16 then
     // spans dozens of cells: its list would run to hundreds) goes to the per-point walk without being listed at
     // all: the traversal of such a box is the list build's own tail (thousands of candidates in one wave).
+    if (strips && (bx1 - bx0) * gg.inv_s0 * ((by1 - by0) * gg.inv_s0) > POINTS_MODE_BLOCK_CELLS) {
+        // far-apart points: the cells would have sent this block to the per-point walk -- say so (PlanParams::points_wanted)
+        if (lane == 0) atomicAdd(a.points_wanted, 1u);
+    }
     if (!strips && (bx1 - bx0) * gg.inv_s0 * ((by1 - by0) * gg.inv_s0) > POINTS_MODE_BLOCK_CELLS && walk_candidates() <= 4.f * (float)cap) {
         for (int t = 0; t < TPW; ++t) {
             if (tile0 + (uint32_t)t >= ntiles) break;
@@ -1517,13 +1524,16 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
         uint32_t longest = ng[t][0] > ng[t][1] ? ng[t][0] : ng[t][1];
         longest = ng[t][2] > longest ? ng[t][2] : longest;
         longest = ng[t][3] > longest ? ng[t][3] : longest;
-        if (longest > POINTS_MODE_MIN_LIST && !strips) {      // (the per-point walk needs the grid)
+        if (longest > POINTS_MODE_MIN_LIST) {      // (strips: the per-point walk needs the grid -- only noted)
             float4 gb[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) gb[g] = lds.gbox[t * 4 + g];
             const float wx = fmaxf(fmaxf(gb[0].z, gb[1].z), fmaxf(gb[2].z, gb[3].z)) - fminf(fminf(gb[0].x, gb[1].x), fminf(gb[2].x, gb[3].x));
             const float wy = fmaxf(fmaxf(gb[0].w, gb[1].w), fmaxf(gb[2].w, gb[3].w)) - fminf(fminf(gb[0].y, gb[1].y), fminf(gb[2].y, gb[3].y));
-            if (wx * gg.inv_s0 * (wy * gg.inv_s0) > POINTS_MODE_MIN_CELLS && walk_candidates() <= 4.f * (float)(longest < cap ? longest : cap)) {
+            if (strips && wx * gg.inv_s0 * (wy * gg.inv_s0) > POINTS_MODE_MIN_CELLS) {
+                if (lane == 0) atomicAdd(a.points_wanted, 1u);
+            }
+            if (!strips && wx * gg.inv_s0 * (wy * gg.inv_s0) > POINTS_MODE_MIN_CELLS && walk_candidates() <= 4.f * (float)(longest < cap ? longest : cap)) {
                 overflow[t] = false; rebuild[t] = false;
                 if (lane < 5)
                     a.hdr[(size_t)(tile0 + (uint32_t)t) * TILE_HDR_WORDS + lane] = lane == 0 ? (TILE_MODE_POINTS << TILE_MODE_SHIFT) : 0u;
@@ -3091,11 +3101,11 @@ struct PointsHint {
     bool strips = false;           // ... and whether that build kept the caller's order
     uint32_t builds = 0;
     hipEvent_t ev = nullptr;
-    uint32_t* host = nullptr;      // pinned {n_points, strip_cover, strips}
+    uint32_t* host = nullptr;      // pinned {n_points, strip_cover, strips, points_wanted}
     uint64_t stamp = 0;
 };
-static_assert(offsetof(PlanParams, strip_cover) == offsetof(PlanParams, n_points) + 4 && offsetof(PlanParams, strips) == offsetof(PlanParams, n_points) + 8,
-              "one copy: n_points, strip_cover, strips");
+static_assert(offsetof(PlanParams, strip_cover) == offsetof(PlanParams, n_points) + 4 && offsetof(PlanParams, strips) == offsetof(PlanParams, n_points) + 8 &&
+              offsetof(PlanParams, points_wanted) == offsetof(PlanParams, n_points) + 12, "one copy: n_points, strip_cover, strips, points_wanted");
 static PointsHint g_phints[16];
 static void phint_poll(PointsHint& h) {          // g_hint_mu held
     if (!h.pending) return;
@@ -3103,7 +3113,7 @@ static void phint_poll(PointsHint& h) {          // g_hint_mu held
     (void)hipGetLastError();
     if (q == hipSuccess) {
         h.pending = false;
-        h.has_points = h.host[0] != 0u;
+        h.has_points = h.host[0] != 0u || h.host[3] != 0u;
         memcpy(&h.cover, &h.host[1], sizeof(float));
         if (!(h.cover >= 0.f)) h.cover = 3.0e38f;      // NaN: as bad as it gets
         h.strips = h.host[2] != 0u;
@@ -3125,7 +3135,7 @@ static PointsHint* phint_entry(int device, int64_t N, int64_t M, bool create) { 
     }
     if (lru->ev && lru->device != device) { (void)hipEventDestroy(lru->ev); lru->ev = nullptr; }
     if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
-    if (!lru->host && hipHostMalloc((void**)&lru->host, 3 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (!lru->host && hipHostMalloc((void**)&lru->host, 4 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
     lru->device = device; lru->N = N; lru->M = M; lru->has_points = false; lru->pending = false; lru->builds = 0; lru->stamp = ++g_hint_clock;
     lru->cover = -1.f; lru->strips = false;
     return lru;
@@ -3161,7 +3171,10 @@ static bool plan_takes_strips(int64_t N, int64_t M, bool with_samples, hipStream
     PointsHint* h = phint_entry(dev, N, M, false);
     if (!h) return false;
     if (!cap) phint_poll(*h);
-    return h->cover >= 0.f && h->cover <= STRIP_MAX_COVER;
+    // (tiles of far-apart points -- a cloud's thin outskirts -- are walked point by point through the GRID at sampling
+    // time, TILE_MODE_POINTS: a plan that had such tiles keeps the cells.  Measured without this line: clamped normals
+    // sigma = 0.15 over lattice Gaussians, warm step 111 -> 1 126 us.)
+    return h->cover >= 0.f && h->cover <= STRIP_MAX_COVER && !h->has_points;
 }
 static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t stream) {      // behind a list build
     if (stream_capturing(stream)) return;
@@ -3175,7 +3188,7 @@ static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t st
     // Gaussians that stopped meeting it should not be met 15 more times)
     if (h->pending || (nth >= 2u && (nth & (h->strips ? 3u : 15u)) != 0u)) return;
     const PlanParams* pp = (const PlanParams*)((const char*)ws + p.off_params);
-    if (hipMemcpyAsync(h->host, &pp->n_points, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+    if (hipMemcpyAsync(h->host, &pp->n_points, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
         h->pending = true;
     (void)hipGetLastError();
@@ -3193,6 +3206,7 @@ static ListArgs make_list_args(const PlanLayout& p, const SamplesLayout& s, void
     la.glist = (uint32_t*)((char*)ws + p.off_glist);
     la.ptiles = (uint32_t*)((char*)ws + p.off_ptiles);
     la.n_points = &((PlanParams*)((char*)ws + p.off_params))->n_points;
+    la.points_wanted = &((PlanParams*)((char*)ws + p.off_params))->points_wanted;
     la.parea = (const float*)((char*)ws + p.off_parea);
     la.strip_cover = &((PlanParams*)((char*)ws + p.off_params))->strip_cover;
     return la;

@@ -163,3 +163,38 @@ def test_strips_through_training_steps(Sampler, hip_lib, monkeypatch):
         args = [x.detach().cpu().double().numpy() for x in (t[0], t[2], t[1])]
         em, ec, ev = c_oracle.backward(*args, pts_np, {k: w.cpu().double().numpy() for k, w in enumerate(r)})
         assert rel(grads[0], em) < 1e-5 and rel(grads[1], ev) < 1e-5 and rel(grads[2], ec) < 1e-5
+
+
+def test_a_cloud_with_thin_outskirts_keeps_the_cells(Sampler, hip_lib):
+    """Tiles of far-apart points are walked point by point through the grid at sampling time (TILE_MODE_POINTS): lattice
+    Gaussians under a clamped-normal cloud must stay with the cells -- whether the library learns it from a build through
+    the cells (its queue of such tiles) or, with the strips forced for a while, from what a strips build noted."""
+    from tools.prof_step import list_stats
+    rng = np.random.default_rng(59)
+    g = lattice(64, 64, 0.5, seed=5)
+    t = [dev32(a) for a in (g[0], g[2], g[1])]
+    pts_np = np.clip(rng.normal(0, 0.15, (150000, 2)), -1, 1).astype(np.float32).astype(np.float64)
+    pts = dev32(pts_np)
+    idx = np.arange(0, pts_np.shape[0], 37)[:3000]
+    exp = c_oracle.forward(*[x.cpu().double().numpy() for x in (t[0], t[2], t[1])], pts_np[idx], orders=(0, 1, 2))
+
+    def run(s):
+        with torch.no_grad():
+            s.preprocess(t[0], t[1], None, t[2], pts)
+            outs = s.sample((0, 1, 2))
+        torch.cuda.synchronize()
+        for o in range(3):
+            assert rel(outs[o][torch.as_tensor(idx, device="cuda")], exp[o]) < 1e-5
+        return strips_of(s, hip_lib)
+
+    with strips_env(None):
+        s = Sampler(False, backend="binned", fuse="all")
+        kinds = [run(s) for _ in range(8)]
+        assert list_stats(s._plan)["points_tiles"] > 0
+        assert kinds == [0] * 8, kinds
+    with strips_env("1"):                      # forced: right, and slower
+        s1 = Sampler(False, backend="binned", fuse="all")
+        assert [run(s1) for _ in range(6)][-1] == 1
+    with strips_env(None):                     # the memory has what the strips builds noted: back to the cells
+        kinds = [run(s1) for _ in range(3)]
+        assert kinds[-1] == 0, kinds
