@@ -198,3 +198,11 @@ def test_a_cloud_with_thin_outskirts_keeps_the_cells(Sampler, hip_lib):
     with strips_env(None):                     # the memory has what the strips builds noted: back to the cells
         kinds = [run(s1) for _ in range(3)]
         assert kinds[-1] == 0, kinds
+
+
+def test_a_captured_step_with_strips_replays_on_new_gaussians(hip_lib):
+    """preprocess + forward + backward captured into a hipGraph with the strips forced, replayed on moved Gaussians
+    (tests/test_graph_gpu.py's recipe: every replay against the oracle)."""
+    from test_graph_gpu import test_captured_step_replays_on_new_parameters as captured_step
+    with strips_env("1"):
+        captured_step(hip_lib, "binned", 48, 96)
