@@ -1478,18 +1478,23 @@ __device__ __forceinline__ void build_block_lists(const ListArgs& a, ListsLds<TP
     walk_rect(bx0, by0, bx1, by1, true,
              [](int, uint32_t, uint32_t) {},
              [&](const float4 A, const float4 B, uint64_t mask, uint32_t j) __attribute__((always_inline)) {
+        // The survivors wait until the buffer cannot take the batch in hand (round 4: it used to be flushed as soon as
+        // a FULL batch might not fit any more, i.e. from 65 on -- a block's ~100 survivors then went through the per-tile
+        // filter and the group tests in two portions, twice the steps of one; a walk that finds them in batches of ~25,
+        // four strips of 16 candidates, more often still).
+        const int add = __builtin_popcountll(mask);
+#ifdef PIGS_LISTS_PROBE_NO_FLUSH          // probe build: the traversal alone (survivors dropped)
+        if (sn + add > SURV_CAP) sn = 0;
+#else
+        if (sn + add > SURV_CAP) flush();
+#endif
         if (mask >> lane & 1ull) {
             const Ellipse e = ellipse_of(A, B.x);
             const int k = sn + lanes_below(mask);
             lds.sa[k] = A;
             lds.sb[k] = make_float4(B.x, e.nb_c, e.nb_a, __builtin_bit_cast(float, j));
         }
-        sn += __builtin_popcountll(mask);
-#ifdef PIGS_LISTS_PROBE_NO_FLUSH          // probe build: the traversal alone (survivors dropped)
-        if (sn > SURV_CAP - 64) sn = 0;
-#else
-        if (sn > SURV_CAP - 64) flush();
-#endif
+        sn += add;
     });
 #ifndef PIGS_LISTS_PROBE_NO_FLUSH
     if (sn > 0) flush();
@@ -3157,13 +3162,12 @@ static bool plan_expects_points(int64_t N, int64_t M, hipStream_t stream) {
 // PIGS_GAUSS_STRIPS=0 / 1: never / always.
 constexpr float STRIP_MAX_COVER = 64.f;
 constexpr int64_t STRIP_MIN_GAUSSIANS = 1024;      // (below, the chain it replaces is not what a step waits for)
-static bool plan_takes_strips(int64_t N, int64_t M, bool with_samples, hipStream_t stream) {
+static bool plan_takes_strips(int64_t N, int64_t M, hipStream_t stream) {
     if (const char* e = getenv("PIGS_GAUSS_STRIPS")) return e[0] == '1';
-    // a build that sorts or looks at the samples too has its launches anyway -- the Gaussians' count, scan and scatter ride
-    // along in them -- and the lists from strips take ~3.5 us longer at C3 than the lists from cells (25.3 against 21.7 us):
-    // only builds on a finished samples workspace keep the caller's order (C3 65.5 -> 59.9 us, kappa 1.3 197 -> 186,
-    // BASELINE configs[1]'s sizes 32.0 -> 21.9: sums of kernel averages, same box)
-    if (with_samples || N < STRIP_MIN_GAUSSIANS) return false;
+    // (a build that also sorts or looks at the samples saves no launch by it -- the Gaussians' count, scan and scatter ride
+    // along in launches that exist anyway -- but the lists from strips are the faster ones since the survivors wait for a
+    // full buffer: 20.0 against 21.3 us at C3, 55 against 60 at kappa 1.3, and the scan / scatter launches carry less)
+    if (N < STRIP_MIN_GAUSSIANS) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
     const bool cap = stream_capturing(stream);
@@ -3264,7 +3268,7 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     // Gaussians whose order in the caller's array is already spatial keep it (PlanParams::strips): one pass instead of
     // count, scan and scatter
     const bool strips = do_plan && build_lists && !defer_lists && !no_lookback && !PIGS_FUSED_BUILD && !PIGS_BWD_BLOCK &&
-                        plan_takes_strips(N, M, do_samples, stream);
+                        plan_takes_strips(N, M, stream);
     a.strips = strips;
     if (ahead) {
         a.s_blocks = (uint32_t)((M + 1023) / 1024);
