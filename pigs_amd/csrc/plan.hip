@@ -3008,8 +3008,9 @@ static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t st
     if (!h) return;
     const uint32_t nth = h->builds++;
     // (with a row length in the memory the build runs on expectations -- an eighth of the count's workgroups, the
-    // Gaussians one launch ahead -- and a point set that stopped meeting them should not be met 15 more times)
-    if (h->pending || (nth >= 2u && (nth & (h->rf ? 3u : 15u)) != 0u)) return;
+    // Gaussians one launch ahead -- and a point set that stopped meeting them should not be met 15 more times: every 8th
+    // build then; the copy is a ~4 us blit in the build's stream)
+    if (h->pending || (nth >= 2u && (nth & (h->rf ? 7u : 15u)) != 0u)) return;
     const SampleParams* sp = (const SampleParams*)((const char*)sws + s.off_params);
     if (hipMemcpyAsync(h->host, sp, HINT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
@@ -3190,7 +3191,7 @@ static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t st
     const uint32_t nth = h->builds++;
     // (builds that keep the caller's order run on an expectation -- strips that cover the domain a few times over -- and
     // Gaussians that stopped meeting it should not be met 15 more times)
-    if (h->pending || (nth >= 2u && (nth & (h->strips ? 3u : 15u)) != 0u)) return;
+    if (h->pending || (nth >= 2u && (nth & (h->strips ? 7u : 15u)) != 0u)) return;
     const PlanParams* pp = (const PlanParams*)((const char*)ws + p.off_params);
     if (hipMemcpyAsync(h->host, &pp->n_points, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
