@@ -137,6 +137,10 @@ struct SampleParams {
     // points -- the sampling kernels read them where the caller keeps them, through the index arithmetic -- so the
     // array must stay valid and unmodified for as long as the workspace is used (the hosts keep the tensor).
     uint64_t src;
+    // two device-wide barriers among the samples' workgroups of the count launch (plan.hip, samples_sort_in_count:
+    // points that were expected to be a lattice and are none are counted, scanned and scattered in that one launch);
+    // zeroed by the first launch of every samples build
+    uint32_t bar[2 * 17];
 };
 
 // ---- index-tiled order: position in `spts` <-> index in the caller's array -------------------

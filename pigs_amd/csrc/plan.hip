@@ -126,6 +126,9 @@ struct BuildArgs {
     int ahead;
     float hint_box[4];
     int s_scan_in_scatter;  // launch 3 of the chain above: no scan launch ran for the samples
+    int sort_in_count;      // ... or no launch 3 at all (ahead && strips: it would hold nothing but the samples' fall-back):
+                            // points that are no lattice are counted, scanned AND scattered by the samples' workgroups
+                            // of launch 2, behind two device-wide barriers among them (samples_sort_in_count)
     // STRIPS (plan.h, PlanParams::strips): the Gaussians keep the caller's order -- gauss_pack_part instead of count,
     // scan and scatter; `parea` is written by builds of either kind (the statistic the library decides from)
     int strips;
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     const uint32_t nblocks = a.bbox_blocks;             // (the launch may hold the Gaussians' workgroups behind these)
     zero_words(a.szero, a.s_zero_words, blockIdx.x, nblocks);
     if (blockIdx.x == 0 && tid < 2) a.sparams->order_stat[tid] = 0u;
+    if (blockIdx.x == 0 && tid < 2 * 17) a.sparams->bar[tid] = 0u;
     if (a.do_plan && !a.ahead) {        // (ahead: a clean workspace, and its counters are being counted in this very launch)
         zero_words(a.counts, a.zero_words, blockIdx.x, nblocks);
         if (a.zero_gacc) zero_words((uint32_t*)a.gacc, 8u * a.N, blockIdx.x, nblocks);
@@ -571,6 +575,37 @@ __device__ __forceinline__ void gauss_count_ahead(const BuildArgs& a, uint32_t b
 
 template <bool COH>
 __device__ __forceinline__ void scan_block(const BuildArgs& a, bool seg0, uint32_t b, uint32_t* sh, uint32_t* sh2);
+__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t G, uint32_t id);
+
+// BuildArgs::sort_in_count: the rest of a one-pass sort behind the count, in the count's own launch -- for points that
+// were expected to be a lattice (so that the host launched nothing behind this for them) and are none.  `ns` sample
+// workgroups (all resident: the host launches at most 256), this one the `sid`-th: everybody's counters are final behind
+// the first barrier; the scan's blocks are dealt out in turn (every workgroup takes its blocks in rising order and a
+// block looks back at lower ones only: nobody waits on somebody who waits on him), past the caches; behind the second
+// barrier every thread moves the points it keyed itself.  Slow next to three launches (two device-wide barriers), and
+// rare: the memory turns around.
+__device__ __forceinline__ void samples_sort_in_count(const BuildArgs& a, uint32_t sid, uint32_t ns, uint32_t* sh, uint32_t* sh2, int lane) {
+    grid_barrier(&a.sparams->bar[0], ns, sid);
+    for (uint32_t b = sid; b < a.s_scan_blocks; b += ns) {
+        scan_block<true>(a, false, b, sh, sh2);
+        __syncthreads();                      // sh / sh2 are the next block's
+    }
+    grid_barrier(&a.sparams->bar[17], ns, sid);
+    for (uint32_t sb = sid; sb < a.s_blocks; sb += ns) {
+        const uint32_t i0 = (sb * 4 + (threadIdx.x >> 6)) * 256 + (uint32_t)lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64 * k;
+            if (i < a.M) {
+                const uint2 kr = a.skey[i];          // (this thread's own store)
+                const float2 p = ((const float2*)a.samples)[i];
+                SPoint sp;
+                sp.x = p.x; sp.y = p.y; sp.m = i;
+                a.spts[__hip_atomic_load(&a.sstarts[kr.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + kr.y] = sp;
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
     __shared__ float shb[4][8];
@@ -631,7 +666,7 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
         // index-tiled: nothing to key, count or move (block-uniform)
     } else if (a.coarse) {
         samples_hist_part(a, bid - gblocks, sg, lh, lane);
-    } else
+    } else {
     // the one-pass count: a sample workgroup takes 1 024 points at a time -- one block where the launch has a workgroup
     // per block; where the host expected a lattice (rf_hint) and launched an eighth of them, the workgroups stride
     // over the blocks: the points that were no lattice after all are still all counted, by fewer hands
@@ -675,6 +710,8 @@ __global__ __launch_bounds__(256) void plan_count_kernel(BuildArgs a) {
             }
             if (lane == 0) { atomicAdd(&a.sparams->order_stat[0], runs); atomicAdd(&a.sparams->order_stat[1], pts); }
         }
+    }
+    if (a.sort_in_count) samples_sort_in_count(a, bid - gblocks, nb - gblocks, scan_sh, scan_sh2, lane);      // (launch-uniform)
     }
 }
 
@@ -1129,11 +1166,13 @@ constexpr uint32_t FUSED_BUILD_MAX_BLOCKS = 256;
 // counts the group in, the last group raises eight release flags and every workgroup polls its own group's
 // (32 pollers per address).
 constexpr int BAR_WORDS = 17;
-__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t G) {
+__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t G, uint32_t id);
+__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t G) { grid_barrier(bar, G, blockIdx.x); }
+__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t G, uint32_t id) {      // id: this workgroup among the G that meet
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's memory operations have completed
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t grp = blockIdx.x & 7u;
+        const uint32_t grp = id & 7u;
         const uint32_t in_grp = (G - grp + 7u) >> 3, groups = G < 8u ? G : 8u;
         if (__hip_atomic_fetch_add(&bar[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1u) {
             if (__hip_atomic_fetch_add(&bar[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u) {
@@ -3271,11 +3310,19 @@ static int run_build(bool do_samples, bool do_plan, bool plan_ws_clean, bool no_
     const bool strips = do_plan && build_lists && !defer_lists && !no_lookback && !PIGS_FUSED_BUILD && !PIGS_BWD_BLOCK &&
                         plan_takes_strips(N, M, stream);
     a.strips = strips;
-    if (ahead) {
+    if (ahead && strips) {
+        // nothing of the Gaussians is left for launches 2 and 3: the samples' fall-back moves into launch 2 whole
+        // (samples_sort_in_count; at most 256 workgroups: they meet at device-wide barriers) -- FOUR launches up to the forward
+        a.sort_in_count = 1; a.s_scan_in_scatter = 0;
+        a.s_blocks = (uint32_t)((M + 1023) / 1024);
+        const uint32_t swgs = (a.s_blocks + 7u) / 8u < 256u ? (a.s_blocks + 7u) / 8u : 256u;
+        hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks + gb), dim3(BBOX_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(plan_count_kernel, dim3(swgs), dim3(256), 0, stream, a);
+    } else if (ahead) {
         a.s_blocks = (uint32_t)((M + 1023) / 1024);
         hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks + gb), dim3(BBOX_THREADS), 0, stream, a);
-        hipLaunchKernelGGL(plan_count_kernel, dim3((strips ? 0u : p.scan_blocks) + (a.s_blocks + 7u) / 8u), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(plan_scatter_kernel, dim3((strips ? 0u : gb) + (uint32_t)((M + 255) / 256)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_count_kernel, dim3(p.scan_blocks + (a.s_blocks + 7u) / 8u), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(plan_scatter_kernel, dim3(gb + (uint32_t)((M + 255) / 256)), dim3(256), 0, stream, a);
     } else
     if (do_samples) hipLaunchKernelGGL(samples_bbox_kernel, dim3(a.bbox_blocks), dim3(BBOX_THREADS), 0, stream, a);
     else if (!plan_ws_clean) hipLaunchKernelGGL(plan_zero_kernel, dim3(64), dim3(256), 0, stream, a);

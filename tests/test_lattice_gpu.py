@@ -229,7 +229,8 @@ def test_a_rank_s_rows_of_the_weak_scaling_grid_are_index_tiled(Sampler, hip_lib
         assert rel(outs[o][idx], exp[o]) < 1e-5
 
 
-def test_gaussians_one_launch_ahead_and_points_that_break_the_expectation(Sampler, hip_lib, monkeypatch):
+@pytest.mark.parametrize("strips", ["0", "1"])
+def test_gaussians_one_launch_ahead_and_points_that_break_the_expectation(Sampler, hip_lib, monkeypatch, strips):
     """With a lattice expected and the same bounding box in the last two completed builds of a size, the Gaussians are
     binned on the REMEMBERED box in the launch that looks at the points (plan.hip, BuildArgs::ahead): three launches
     in front of the tile lists instead of four.  Results must not depend on it -- not when the Gaussians change, not
@@ -237,6 +238,10 @@ def test_gaussians_one_launch_ahead_and_points_that_break_the_expectation(Sample
     never wrong), not when it is no lattice at all (its workgroups scan and scatter in the third launch)."""
     from oracle import c_oracle
     monkeypatch.setenv("PIGS_LATTICE", "1")
+    # strips = "1": the Gaussians keep the caller's order (PIGS_GAUSS_STRIPS) -- nothing of them is left for the second and
+    # third launch then, there is no third, and points that are no lattice after all are counted, scanned and scattered
+    # inside the second, behind device-wide barriers (plan.hip, samples_sort_in_count)
+    monkeypatch.setenv("PIGS_GAUSS_STRIPS", strips)
     rng = np.random.default_rng(31)
     g = grid(96, 64)
     s = Sampler(False, backend="binned", fuse="all", reuse_samples=False)
@@ -265,3 +270,39 @@ def test_gaussians_one_launch_ahead_and_points_that_break_the_expectation(Sample
         run(rng.uniform(-1, 1, g.shape))                        # ... until the memory has turned around
     for _ in range(6):
         assert run(g) == (96, 64)                               # and back
+
+
+def test_a_million_points_that_stop_being_a_lattice_are_sorted_inside_the_count_launch(Sampler, hip_lib, monkeypatch):
+    """The same at C3's size (1024^2 points, 256 sample workgroups striding over 1 024 blocks, 65 scan blocks dealt out
+    among them): lattice, lattice, ..., then a permutation of it and uniform random points -- every result against the
+    dense HIP path on a slice, and against the sorted build of the same points."""
+    monkeypatch.setenv("PIGS_GAUSS_STRIPS", "1")
+    from pigs_amd import synthetic
+    gs = synthetic.lattice_gaussians(64, 64, 0.5, seed=1)
+    t = {k: v.float().cuda() for k, v in gs.items()}
+    lat = synthetic.grid_samples(1024).float().cuda()
+    gen = torch.Generator().manual_seed(3)
+    others = [lat[torch.randperm(lat.shape[0], generator=gen).cuda()], (torch.rand(lat.shape, generator=gen) * 2 - 1).cuda()]
+    s = Sampler(False, backend="binned", fuse="all", reuse_samples=False)
+
+    def run(pts):
+        with torch.no_grad():
+            s.preprocess(t["means"], t["values"], None, t["conics"], pts)
+            outs = [o.clone() for o in s.sample((0, 1, 2))]
+        torch.cuda.synchronize()
+        return outs, lattice_of(s, hip_lib)
+
+    for _ in range(5):
+        assert run(lat)[1] == (1024, 1024)
+    idx = torch.arange(0, lat.shape[0], 997, device="cuda")[:1024]
+    for pts in others:
+        outs, kind = run(pts)                      # expected a lattice: sorted inside the count launch
+        assert kind == (0, 0)
+        d = Sampler(False, backend="dense")
+        with torch.no_grad():
+            d.preprocess(t["means"], t["values"], None, t["conics"], pts[idx].contiguous())
+            ref = d.sample((0, 1, 2))
+        for o in range(3):
+            assert rel(outs[o][idx], ref[o].cpu().double().numpy()) < 2e-5
+        assert bool(torch.isfinite(outs[2]).all())
+    assert run(lat)[1] == (1024, 1024)
