@@ -227,8 +227,8 @@ size_t pigs_plan_error_offset(void);
  * results never depend on it; PIGS_LATTICE=0 / 1 in the environment: never / at every size.
  * When the library expects a lattice (the last completed build of this size was one) and that build and the one before it
  * had the same bounding box, pigs_plan_build with PIGS_BUILD_SAMPLES | PIGS_BUILD_PLAN_WS_CLEAN bins the Gaussians on
- * the REMEMBERED box beside its first look at the points (one launch fewer; a grid's domain steers the quality of the
- * binning, never a result; PIGS_NO_AHEAD in the environment switches it off).
+ * the REMEMBERED box beside its first look at the points (one launch fewer, two with Gaussians in strips, below; a grid's
+ * domain steers the quality of the binning, never a result; PIGS_NO_AHEAD in the environment switches it off).
  * CONTRACT that comes with it: a samples workspace in index-tiled order holds the ADDRESS of `samples`, not the
  * points; pigs_plan_build / pigs_plan_forward / pigs_plan_backward / pigs_residual_* read the caller's array
  * through it.  `samples` must therefore stay allocated and unmodified for as long as the samples workspace is
