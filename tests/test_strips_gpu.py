@@ -1,5 +1,5 @@
 """GPU: builds that keep the Gaussians in the CALLER's order (include/pigs_amd.h, pigs_plan_strips_offset; plan.h,
-PlanParams::strips): every 64 consecutive Gaussians are a strip with a bounding box, the tile lists come from the strip
+PlanParams::strips): every 16 consecutive Gaussians are a strip with a bounding box (16 strips a super-strip), the tile lists come from the strip
 boxes -- no count, scan or scatter.  Results must be the oracle's whatever the order of the Gaussians (a lattice as the
 reference lays it out, /root/reference/model_pn.py:338-342; a shuffled one: every strip then reaches everywhere), and
 the library must take the strips only for Gaussians whose strips cover the domain a few times over."""
