@@ -2944,6 +2944,7 @@ struct OrderHint {
     float box[4] = {0.f, 0.f, 0.f, 0.f};   // the samples' bounding box of the last completed build
     bool box_seen = false;         // ... and whether the completed build before it had the same one: a box to build the
     bool box_stable = false;       //     Gaussians' grid on before this build's own is known (BuildArgs::ahead)
+    uint32_t same = 0;             // completed copies in a row that said the same (row length, box): the copies get rarer
     uint64_t stamp = 0;
 };
 constexpr uint32_t HINT_WORDS = 16;
@@ -2977,7 +2978,7 @@ static OrderHint* hint_entry(int device, int64_t M, bool create) {      // g_hin
     if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
     if (!lru->host && hipHostMalloc((void**)&lru->host, HINT_WORDS * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
     lru->device = device; lru->M = M; lru->coarse = false; lru->pending = false; lru->builds = 0; lru->rf = 0; lru->stamp = ++g_hint_clock;
-    lru->box_seen = lru->box_stable = false;
+    lru->box_seen = lru->box_stable = false; lru->same = 0;
     return lru;
 }
 
@@ -2993,6 +2994,7 @@ static void hint_poll(OrderHint& h) {           // g_hint_mu held
     (void)hipGetLastError();          // hipErrorNotReady is an answer, not a failure
     if (q == hipSuccess) {
         h.pending = false;
+        const uint32_t rf_before = h.rf;
         h.rf = h.host[14];         // SampleParams::lat[0]
         if (h.rf != 0u) h.coarse = false;      // index-tiled: the points arrived in order (and left no run statistic)
         else if (h.host[11] > 0u) h.coarse = (uint64_t)h.host[10] * 100u > (uint64_t)h.host[11] * 55u;
@@ -3000,6 +3002,7 @@ static void hint_poll(OrderHint& h) {           // g_hint_mu held
         memcpy(b, h.host, sizeof(b));
         const bool finite = fabsf(b[0]) < 3.0e38f && fabsf(b[1]) < 3.0e38f && fabsf(b[2]) < 3.0e38f && fabsf(b[3]) < 3.0e38f && b[2] > b[0] && b[3] > b[1];
         h.box_stable = finite && h.box_seen && memcmp(b, h.box, sizeof(b)) == 0;
+        h.same = h.box_stable && h.rf == rf_before ? h.same + 1u : 0u;
         h.box_seen = finite;
         memcpy(h.box, b, sizeof(b));
     }
@@ -3049,7 +3052,8 @@ static void samples_note_order(const SamplesLayout& s, void* sws, hipStream_t st
     // (with a row length in the memory the build runs on expectations -- an eighth of the count's workgroups, the
     // Gaussians one launch ahead -- and a point set that stopped meeting them should not be met 15 more times: every 8th
     // build then; the copy is a ~4 us blit in the build's stream)
-    if (h->pending || (nth >= 2u && (nth & (h->rf ? 7u : 15u)) != 0u)) return;
+    // ... every 32nd once three copies in a row have said the same)
+    if (h->pending || (nth >= 2u && (nth & (h->rf ? (h->same >= 2u ? 31u : 7u) : 15u)) != 0u)) return;
     const SampleParams* sp = (const SampleParams*)((const char*)sws + s.off_params);
     if (hipMemcpyAsync(h->host, sp, HINT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
@@ -3138,12 +3142,14 @@ static bool defer_take(const void* ws, DeferredLists& d) {
 // per device and (N, M): behind the list build of the first two plans of a size and of every 16th, PlanParams::
 // n_points is copied to pinned memory on the build's stream (nobody waits); a first forward takes the fused launch
 // unless the last completed copy for its sizes showed such tiles.  Never inside a capture.
+constexpr float STRIP_MAX_COVER = 64.f;      // (plan_takes_strips below)
 struct PointsHint {
     int device = -1;
     int64_t N = 0, M = 0;
     bool has_points = false, pending = false;
     float cover = -1.f;            // PlanParams::strip_cover of the last completed build (< 0: none yet)
     bool strips = false;           // ... and whether that build kept the caller's order
+    uint32_t same = 0;             // completed copies in a row that led to the same choice: the copies get rarer
     uint32_t builds = 0;
     hipEvent_t ev = nullptr;
     uint32_t* host = nullptr;      // pinned {n_points, strip_cover, strips, points_wanted}
@@ -3158,10 +3164,12 @@ static void phint_poll(PointsHint& h) {          // g_hint_mu held
     (void)hipGetLastError();
     if (q == hipSuccess) {
         h.pending = false;
+        const bool took_before = h.cover >= 0.f && h.cover <= STRIP_MAX_COVER && !h.has_points;
         h.has_points = h.host[0] != 0u || h.host[3] != 0u;
         memcpy(&h.cover, &h.host[1], sizeof(float));
         if (!(h.cover >= 0.f)) h.cover = 3.0e38f;      // NaN: as bad as it gets
         h.strips = h.host[2] != 0u;
+        h.same = (h.cover <= STRIP_MAX_COVER && !h.has_points) == took_before ? h.same + 1u : 0u;
     }
 }
 static PointsHint* phint_entry(int device, int64_t N, int64_t M, bool create) {      // g_hint_mu held
@@ -3182,7 +3190,7 @@ static PointsHint* phint_entry(int device, int64_t N, int64_t M, bool create) { 
     if (!lru->ev && hipEventCreateWithFlags(&lru->ev, hipEventDisableTiming) != hipSuccess) { lru->ev = nullptr; (void)hipGetLastError(); return nullptr; }
     if (!lru->host && hipHostMalloc((void**)&lru->host, 4 * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) { lru->host = nullptr; (void)hipGetLastError(); return nullptr; }
     lru->device = device; lru->N = N; lru->M = M; lru->has_points = false; lru->pending = false; lru->builds = 0; lru->stamp = ++g_hint_clock;
-    lru->cover = -1.f; lru->strips = false;
+    lru->cover = -1.f; lru->strips = false; lru->same = 0;
     return lru;
 }
 static bool plan_expects_points(int64_t N, int64_t M, hipStream_t stream) {
@@ -3200,7 +3208,6 @@ static bool plan_expects_points(int64_t N, int64_t M, hipStream_t stream) {
 // tiles meets (a lattice in row order, a strip of 1 x 16 widened by its ellipses' reach on every side: ~10 times at
 // kappa = 0.5, ~17 at 0.8, ~33 at 1.3; Gaussians in no order: every strip covers the domain, N / 16 times).
 // PIGS_GAUSS_STRIPS=0 / 1: never / always.
-constexpr float STRIP_MAX_COVER = 64.f;
 constexpr int64_t STRIP_MIN_GAUSSIANS = 1024;      // (below, the chain it replaces is not what a step waits for)
 static bool plan_takes_strips(int64_t N, int64_t M, hipStream_t stream) {
     if (const char* e = getenv("PIGS_GAUSS_STRIPS")) return e[0] == '1';
@@ -3230,7 +3237,7 @@ static void plan_note_points(const PlanLayout& p, const void* ws, hipStream_t st
     const uint32_t nth = h->builds++;
     // (builds that keep the caller's order run on an expectation -- strips that cover the domain a few times over -- and
     // Gaussians that stopped meeting it should not be met 15 more times)
-    if (h->pending || (nth >= 2u && (nth & (h->strips ? 7u : 15u)) != 0u)) return;
+    if (h->pending || (nth >= 2u && (nth & (h->strips ? (h->same >= 2u ? 31u : 7u) : 15u)) != 0u)) return;
     const PlanParams* pp = (const PlanParams*)((const char*)ws + p.off_params);
     if (hipMemcpyAsync(h->host, &pp->n_points, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipEventRecord(h->ev, stream) == hipSuccess)
