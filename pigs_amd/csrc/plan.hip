@@ -291,7 +291,13 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
     // Thread t looks at the eight steps from point 8 t on; the loads are issued HERE and looked at behind the pass:
     // one memory round trip for the launch.
     constexpr uint32_t NONE = 0xffffffffu;
-    const bool search = !a.no_lattice && n >= 64u;
+    // With a row length remembered (rf_hint) there is nothing to search for: the pass below runs on it, and a point set
+    // whose rows are not that long fails it (the row ends it did not expect are neighbour steps as wide as the domain) --
+    // it is sorted this once, the memory forgets the row length, the next build searches again.  (The search walks up to
+    // 16 385 points in every workgroup: rows of 2 880 points -- a rank's shard of bench.py's grid for 8 GPUs -- made the
+    // first launch 21 us instead of 8.)
+    const bool hinted = !a.no_lattice && n >= 64u && lattice_shape_ok(a.rf_hint, n);
+    const bool search = !a.no_lattice && n >= 64u && !hinted;
     float2 e0 = make_float2(0.f, 0.f), e1 = e0, q[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) q[k] = e0;
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
             if (8u * tid + (uint32_t)k < n) q[k] = pts[8u * tid + (uint32_t)k];
     }
     // the pass on the remembered row length (or, without one, for the box alone)
-    const uint32_t hf = search && lattice_shape_ok(a.rf_hint, n) ? a.rf_hint : 0u;
+    const uint32_t hf = hinted ? a.rf_hint : 0u;
+    if (hinted) { e0 = pts[0]; e1 = pts[1]; }        // (the fast axis: from the first two points, as the search takes it)
     // (from 2^19 points on, and with no row length expected, the launch has twice the workgroups and a thread half the
     // rows: BuildArgs::bbox_blocks)
     const bool wide = nblocks > 256u;
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void samples_bbox_kernel(BuildArgs a) {
             key = block_min(k2);
         }
     }
-    const uint32_t rf = key == NONE ? 0u : key + 1u;
+    const uint32_t rf = hinted ? hf : key == NONE ? 0u : key + 1u;
     const bool cand = lattice_shape_ok(rf, n);      // block-uniform
     if (cand && rf != hf) {                         // first build of a size, or the points changed shape
         if (wide) pass(std::integral_constant<int, 4>{}, rf, false); else pass(std::integral_constant<int, 8>{}, rf, false);

@@ -306,3 +306,33 @@ def test_a_million_points_that_stop_being_a_lattice_are_sorted_inside_the_count_
             assert rel(outs[o][idx], ref[o].cpu().double().numpy()) < 2e-5
         assert bool(torch.isfinite(outs[2]).all())
     assert run(lat)[1] == (1024, 1024)
+
+
+def test_a_lattice_of_another_shape_and_the_same_count(Sampler, hip_lib, monkeypatch):
+    """With a row length remembered the first launch does not search for one: it verifies the remembered one.  A
+    lattice of the same count and another shape fails that (its row ends are steps as wide as the domain), is sorted,
+    the memory forgets the row length, and a later build finds the new one.  Every build against the oracle."""
+    from oracle import c_oracle
+    monkeypatch.setenv("PIGS_LATTICE", "1")
+    rng = np.random.default_rng(37)
+    means, con, values = random_gaussians(rng, 500, 1, log_sigma_mean=-2.6, log_sigma_std=0.4)
+    t = [dev32(a) for a in (means, values, con)]
+    args = [x.cpu().double().numpy() for x in (t[0], t[2], t[1])]
+    s = Sampler(False, backend="binned", fuse="all", reuse_samples=False)
+
+    def run(g):
+        p = dev32(g)
+        with torch.no_grad():
+            s.preprocess(t[0], t[1], None, t[2], p)
+            outs = s.sample((0, 1, 2))
+        torch.cuda.synchronize()
+        exp = c_oracle.forward(*args, p.cpu().double().numpy(), orders=(0, 1, 2))
+        for o in range(3):
+            assert rel(outs[o], exp[o]) < 1e-5
+        return lattice_of(s, hip_lib)
+
+    a, b = grid(128, 64), grid(64, 128)
+    for _ in range(4):
+        assert run(a) == (128, 64)
+    kinds = [run(b) for _ in range(40)]
+    assert kinds[0] in ((0, 0), (64, 128)) and kinds[-1] == (64, 128), kinds
